@@ -1,0 +1,40 @@
+# Build of the MI355X likelihood engine (gfx950 only), its host mirror and the CPU oracle.
+#   make            -> everything that ships to the GPU box
+#   make ref        -> oracle/_ref (needs /root/reference; container only)
+HIPCC      ?= /opt/rocm/bin/hipcc
+CXX        ?= g++
+CC         ?= gcc
+ARCH       := gfx950
+PKG        := iq-tree_amd
+CSRC       := $(PKG)/csrc
+HOST       := $(PKG)/host
+LIBDIR     := $(PKG)/lib
+HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result
+HIP_SRCS   := $(CSRC)/engine.hip $(CSRC)/kernels_valu4.hip
+HIP_OBJS   := $(patsubst $(CSRC)/%.hip,$(LIBDIR)/%.o,$(HIP_SRCS))
+
+all: $(LIBDIR)/libiqhip.so $(LIBDIR)/libiqhost.so oracle/liblh_oracle.so
+
+$(LIBDIR):
+	mkdir -p $(LIBDIR)
+
+$(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/iqhip_internal.h include/iqhip.h | $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/libiqhip.so: $(HIP_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS)
+
+$(LIBDIR)/libiqhost.so: $(HOST)/phylo_host.cpp $(HOST)/iqhost_c.cpp $(HOST)/phylo_host.h include/iqhip.h $(LIBDIR)/libiqhip.so
+	$(CXX) -O2 -std=c++17 -fPIC -shared -Wall -o $@ $(HOST)/phylo_host.cpp $(HOST)/iqhost_c.cpp \
+	    -L$(LIBDIR) -liqhip -Wl,-rpath,'$$ORIGIN'
+
+oracle/liblh_oracle.so: oracle/lh_oracle.c
+	$(CC) -O3 -mavx -ffp-contract=off -fPIC -shared -Wall -Wextra -o $@ $< -lm
+
+ref:
+	$(MAKE) -C oracle ref
+
+clean:
+	rm -rf $(LIBDIR) oracle/liblh_oracle.so oracle/_ref
+
+.PHONY: all ref clean

@@ -1,0 +1,175 @@
+/*
+ * iqhip.h -- C ABI of the MI355X (gfx950) likelihood engine `libiqhip.so`.
+ *
+ * Drop-in boundary for ONE path of IQ-TREE 1.4.3: the Felsenstein-pruning likelihood
+ * kernels that sit behind PhyloTree's four member-function pointers
+ *   computePartialLikelihoodPointer   phylotree.h:658-659   (kernel: phylokernel.h:70-483)
+ *   computeLikelihoodBranchPointer    phylotree.h:697-698   (kernel: phylokernel.h:733-1020)
+ *   computeLikelihoodFromBufferPointer phylotree.h:742-743  (kernel: phylokernel.h:1022-1192)
+ *   computeLikelihoodDervPointer      phylotree.h:979-980   (kernel: phylokernel.h:485-730)
+ * selected by PhyloTree::setLikelihoodKernel (phylotreesse.cpp:60-311).  The reference-side
+ * adapter (four PhyloTree member functions that do the recursion / flag handling and call
+ * this ABI) is shown in INTEGRATION.md and integration/phylotree_hip.cpp.
+ *
+ * Conventions
+ *   - plain C, POD arguments, every call returns an int status (IQHIP_OK == 0); the text of
+ *     the last error of the calling thread is available from iqhip_last_error().  The
+ *     reference has no error codes on this path (outError()/assert, tools.cpp:99-106); the
+ *     adapter turns a non-zero status into outError().
+ *   - one engine == one PhyloTree on one GPU.  No process-global state: engines of
+ *     different trees may be driven from different host threads (phylosupertree.cpp:970).
+ *   - all vectors stay resident in HBM.  A partial-likelihood vector is addressed by an
+ *     opaque 64-bit KEY chosen by the caller -- the adapter uses the value of the host
+ *     pointer PhyloNeighbor::partial_lh (phylonode.h:112), which the tree search re-points
+ *     freely (phylotree.cpp:2921-2922, phylokernel.h:127-143); the engine maps key -> device
+ *     slab lazily.  The companion scale_num array (phylonode.h:122, `short` per pattern)
+ *     lives with the same key.
+ *   - host-layout arrays use the reference's layout: partial_lh[ptn*block + c*nstates + i],
+ *     evec[x*n+i] = U[x][i], inv_evec[i*n+x] = U^-1[i][x]; the device layout
+ *     is private and converted by the fetch/upload calls.
+ *   - patterns may be a shard [first, first+nptn) of the alignment: every result of this
+ *     ABI is then the shard's partial sum; the caller all-reduces (RCCL) the result vector.
+ */
+#ifndef IQHIP_H_
+#define IQHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IQHIP_ABI_VERSION 1
+
+enum {
+    IQHIP_OK = 0,
+    IQHIP_ERR_NO_DEVICE = 1,   /* no HIP device / runtime failure at create */
+    IQHIP_ERR_INVALID = 2,     /* bad argument (shape, key, leaf id, order of calls) */
+    IQHIP_ERR_UNSUPPORTED = 3, /* nstates not in {4,20,64} etc. */
+    IQHIP_ERR_HIP = 4,         /* a HIP runtime call failed; see iqhip_last_error() */
+    IQHIP_ERR_NOMEM = 5
+};
+
+typedef struct iqhip_engine iqhip_engine;
+
+/* One internal-node update = one call of computePartialLikelihoodEigenSIMD's pattern loop
+ * (phylokernel.h:183-479).  A child is a leaf when *_leaf >= 0 (taxon id = row of the
+ * alignment passed to iqhip_set_alignment); otherwise *_key names a computed vector.
+ * Child order is free: the engine applies the reference's own "leaf goes left" swap
+ * (phylokernel.h:116-121) where it matters. */
+typedef struct iqhip_node_op {
+    uint64_t dst_key;
+    uint64_t left_key;
+    uint64_t right_key;
+    int32_t left_leaf;
+    int32_t right_leaf;
+    double left_len;  /* PhyloNeighbor::length of the left child branch  */
+    double right_len; /* ... of the right child branch */
+} iqhip_node_op;
+
+/* One end of a branch for the lnL / theta calls. leaf >= 0 -> taxon id, else key. */
+typedef struct iqhip_branch_end {
+    uint64_t key;
+    int32_t leaf;
+    int32_t _pad;
+} iqhip_branch_end;
+
+const char *iqhip_last_error(void);
+int iqhip_abi_version(void);
+int iqhip_device_count(void);
+
+/* nstates in {4, 20, 64} (the reference's SIMD dispatch cases phylotreeavx.cpp:34-134;
+ * 2 and other counts use the scalar kernel there and are IQHIP_ERR_UNSUPPORTED here).
+ * nptn = aln->size() + unobserved patterns of this shard; ntaxa = leafNum. */
+int iqhip_create(iqhip_engine **out, int device, int nstates, int ncat, int64_t nptn,
+                 int ntaxa);
+void iqhip_destroy(iqhip_engine *e);
+
+/* Optional: run on the caller's HIP stream (hipStream_t) instead of the engine's own. */
+int iqhip_set_stream(iqhip_engine *e, void *hip_stream);
+/* Pre-allocate device slabs for `nvectors` partial-likelihood vectors (the reference's
+ * central_partial_lh arena, phylotree.cpp:867-873). Optional; slabs are created on demand. */
+int iqhip_reserve(iqhip_engine *e, int nvectors);
+/* Forget a key (PhyloTree::deleteAllPartialLh / aligned_free of an NNI scratch buffer). */
+int iqhip_release(iqhip_engine *e, uint64_t key);
+/* Move a vector to a new key without touching device data (LM_PER_NODE re-orientation is a
+ * pointer move on the host, phylokernel.h:127-143, so the key usually does not change). */
+int iqhip_rekey(iqhip_engine *e, uint64_t old_key, uint64_t new_key);
+
+/* Alignment side inputs (phylotreesse.cpp:531-569, pattern.h:24, alignment.cpp:470-472).
+ * states: ntaxa rows of nptn state bytes (row = taxon id);  ptn_freq, ptn_invar: nptn. */
+int iqhip_set_alignment(iqhip_engine *e, const uint8_t *states, const double *ptn_freq,
+                        const double *ptn_invar);
+int iqhip_set_ptn_freq(iqhip_engine *e, const double *ptn_freq);   /* bootstrap re-weighting */
+int iqhip_set_ptn_invar(iqhip_engine *e, const double *ptn_invar); /* +I changed */
+
+/* Model side inputs (model/modelsubst.h:248-258, model/rateheterogeneity.h:95-141,
+ * phylotreesse.cpp:359-529): eval[n], evec[n*n], inv_evec[n*n], rates[ncat], props[ncat],
+ * tip_partial_lh[(state_unknown+1)*n]. Invalidates nothing by itself: like the reference,
+ * the caller clears partial_lh_computed flags (clearAllPartialLH). */
+int iqhip_set_model(iqhip_engine *e, const double *eval, const double *evec,
+                    const double *inv_evec, const double *rates, const double *props,
+                    int state_unknown, const double *tip_partial_lh);
+
+/* Execute a post-ordered list of node updates (children before parents) in ONE submission.
+ * sum_scale[k] receives op k's own sum_scale (phylokernel.h:389,471: LOG_SCALING_THRESHOLD *
+ * sum of ptn_freq over the patterns rescaled at this node); the caller keeps
+ * lh_scale_factor = left + right + sum_scale exactly as phylokernel.h:157,395,477. */
+int iqhip_update_partials(iqhip_engine *e, const iqhip_node_op *ops, int nops,
+                          double *sum_scale);
+
+/* computeLikelihoodBranchEigenSIMD's pattern loop (phylokernel.h:779-966) on branch (a,b)
+ * of length len.  At most one end may be a leaf.  *lnl = sum_ptn freq*log|lh_ptn| WITHOUT
+ * the two lh_scale_factor terms (the caller adds them, phylokernel.h:751).  _pattern_lh is
+ * kept on the device (iqhip_fetch_pattern_lh). */
+int iqhip_branch_lnl(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b, double len,
+                     double *lnl);
+
+/* Fused form of the reference's hot loop 1 (clearAllPartialLH(); computeLikelihood()):
+ * the node updates and the branch lnL in one device pass. */
+int iqhip_traverse_lnl(iqhip_engine *e, const iqhip_node_op *ops, int nops,
+                       iqhip_branch_end a, iqhip_branch_end b, double len,
+                       double *sum_scale, double *lnl);
+
+/* theta_all = a .* b (phylokernel.h:535-579); kept on the device. */
+int iqhip_compute_theta(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b);
+/* df, ddf at branch length len from theta (phylokernel.h:516-532,583-651). */
+int iqhip_derv(iqhip_engine *e, double len, double *df, double *ddf);
+/* lnL (without lh_scale_factors) from theta (phylokernel.h:1040-1122); writes _pattern_lh. */
+int iqhip_lnl_from_theta(iqhip_engine *e, double len, double *lnl);
+
+/* Sharded / asynchronous use.  The *_async forms enqueue the same work but leave the
+ * result on the device: `iqhip_result_device_ptr` is a device array of
+ * iqhip_result_capacity() doubles laid out as
+ *    [0] = lnl or df, [1] = ddf, [2 .. 2+nops) = sum_scale per op
+ * which the caller may all-reduce in place (ncclAllReduce / torch.distributed, SUM, f64)
+ * on the engine's stream before iqhip_result_read copies it to the host. */
+int iqhip_bind_result_buffer(iqhip_engine *e, void *device_ptr, int capacity_doubles);
+void *iqhip_result_device_ptr(iqhip_engine *e);
+int iqhip_result_capacity(iqhip_engine *e);
+int iqhip_traverse_lnl_async(iqhip_engine *e, const iqhip_node_op *ops, int nops,
+                             iqhip_branch_end a, iqhip_branch_end b, double len);
+int iqhip_derv_async(iqhip_engine *e, double len);
+int iqhip_result_read(iqhip_engine *e, double *out, int ndoubles); /* syncs the stream */
+int iqhip_synchronize(iqhip_engine *e);
+
+/* Lazy device->host views of what the reference keeps in host memory
+ * (phylotree.cpp:1062,1218-1227 read scale_num and _pattern_lh on the host). */
+int iqhip_fetch_scale_num(iqhip_engine *e, uint64_t key, int16_t *out /* nptn */);
+int iqhip_fetch_pattern_lh(iqhip_engine *e, double *out /* nptn */);
+int iqhip_fetch_partial(iqhip_engine *e, uint64_t key, double *out /* nptn*block, ref layout */);
+int iqhip_fetch_theta(iqhip_engine *e, double *out /* nptn*block, ref layout */);
+/* Host -> device (tests; SPR/NNI code that fills a buffer on the host). */
+int iqhip_upload_partial(iqhip_engine *e, uint64_t key, const double *partial_lh,
+                         const int16_t *scale_num);
+
+/* Measurement hook for bench.py: average device time (ms) of the dominant kernel over the
+ * launches since the last reset, measured with HIP events on the engine's stream. */
+int iqhip_timing_enable(iqhip_engine *e, int on);
+int iqhip_timing_read(iqhip_engine *e, double *avg_ms, int64_t *launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IQHIP_H_ */

@@ -1,0 +1,391 @@
+"""iq-tree_amd -- Python plumbing over the MI355X likelihood engine.
+
+The product is two shared libraries built in-tree by `make` (see __graft_entry__.build):
+  lib/libiqhip.so   HIP kernels + the C ABI of include/iqhip.h (the drop-in boundary)
+  lib/libiqhost.so  C++ host mirror of the PhyloTree slice that drives the kernels
+This package only loads them with ctypes; there is no Python or CPU implementation of the
+likelihood path here, and loading fails loudly when the libraries are missing.
+
+The directory name has a hyphen, so it is imported through `__graft_entry__.load_package()`
+(or tests/conftest.py) under the module name `iqtree_amd`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+REPO_ROOT = os.path.dirname(_HERE)
+
+# every symbol include/iqhip.h declares (kept in sync by tests/test_abi.py)
+IQHIP_SYMBOLS = [
+    "iqhip_last_error", "iqhip_abi_version", "iqhip_device_count", "iqhip_create", "iqhip_destroy",
+    "iqhip_set_stream", "iqhip_reserve", "iqhip_release", "iqhip_rekey", "iqhip_set_alignment",
+    "iqhip_set_ptn_freq", "iqhip_set_ptn_invar", "iqhip_set_model", "iqhip_update_partials",
+    "iqhip_branch_lnl", "iqhip_traverse_lnl", "iqhip_compute_theta", "iqhip_derv",
+    "iqhip_lnl_from_theta", "iqhip_bind_result_buffer", "iqhip_result_device_ptr",
+    "iqhip_result_capacity", "iqhip_traverse_lnl_async", "iqhip_derv_async", "iqhip_result_read",
+    "iqhip_synchronize", "iqhip_fetch_scale_num", "iqhip_fetch_pattern_lh", "iqhip_fetch_partial",
+    "iqhip_fetch_theta", "iqhip_upload_partial", "iqhip_timing_enable", "iqhip_timing_read",
+]
+
+
+class NodeOp(C.Structure):
+    """struct iqhip_node_op (include/iqhip.h)."""
+    _fields_ = [("dst_key", C.c_uint64), ("left_key", C.c_uint64), ("right_key", C.c_uint64),
+                ("left_leaf", C.c_int32), ("right_leaf", C.c_int32),
+                ("left_len", C.c_double), ("right_len", C.c_double)]
+
+
+class BranchEnd(C.Structure):
+    """struct iqhip_branch_end (include/iqhip.h)."""
+    _fields_ = [("key", C.c_uint64), ("leaf", C.c_int32), ("_pad", C.c_int32)]
+
+
+def leaf_end(leaf):
+    return BranchEnd(0, int(leaf), 0)
+
+
+def key_end(key):
+    return BranchEnd(int(key), -1, 0)
+
+
+ALLREDUCE_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
+
+_libs = {}
+
+
+def _load(name):
+    if name in _libs:
+        return _libs[name]
+    path = os.path.join(LIB_DIR, name)
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make`). "
+            "There is no CPU fallback for the likelihood path.")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    _libs[name] = lib
+    return lib
+
+
+def libiqhip():
+    lib = _load("libiqhip.so")
+    if getattr(lib, "_iq_typed", False):
+        return lib
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int16)
+    vp = C.c_void_p
+    lib.iqhip_last_error.restype = C.c_char_p
+    lib.iqhip_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int]
+    lib.iqhip_destroy.argtypes = [vp]
+    lib.iqhip_destroy.restype = None
+    lib.iqhip_set_stream.argtypes = [vp, vp]
+    lib.iqhip_reserve.argtypes = [vp, C.c_int]
+    lib.iqhip_release.argtypes = [vp, C.c_uint64]
+    lib.iqhip_rekey.argtypes = [vp, C.c_uint64, C.c_uint64]
+    lib.iqhip_set_alignment.argtypes = [vp, C.POINTER(C.c_uint8), dp, dp]
+    lib.iqhip_set_ptn_freq.argtypes = [vp, dp]
+    lib.iqhip_set_ptn_invar.argtypes = [vp, dp]
+    lib.iqhip_set_model.argtypes = [vp, dp, dp, dp, dp, dp, C.c_int, dp]
+    lib.iqhip_update_partials.argtypes = [vp, C.POINTER(NodeOp), C.c_int, dp]
+    lib.iqhip_branch_lnl.argtypes = [vp, BranchEnd, BranchEnd, C.c_double, dp]
+    lib.iqhip_traverse_lnl.argtypes = [vp, C.POINTER(NodeOp), C.c_int, BranchEnd, BranchEnd,
+                                       C.c_double, dp, dp]
+    lib.iqhip_compute_theta.argtypes = [vp, BranchEnd, BranchEnd]
+    lib.iqhip_derv.argtypes = [vp, C.c_double, dp, dp]
+    lib.iqhip_lnl_from_theta.argtypes = [vp, C.c_double, dp]
+    lib.iqhip_bind_result_buffer.argtypes = [vp, vp, C.c_int]
+    lib.iqhip_result_device_ptr.argtypes = [vp]
+    lib.iqhip_result_device_ptr.restype = vp
+    lib.iqhip_result_capacity.argtypes = [vp]
+    lib.iqhip_traverse_lnl_async.argtypes = [vp, C.POINTER(NodeOp), C.c_int, BranchEnd, BranchEnd,
+                                             C.c_double]
+    lib.iqhip_derv_async.argtypes = [vp, C.c_double]
+    lib.iqhip_result_read.argtypes = [vp, dp, C.c_int]
+    lib.iqhip_synchronize.argtypes = [vp]
+    lib.iqhip_fetch_scale_num.argtypes = [vp, C.c_uint64, ip]
+    lib.iqhip_fetch_pattern_lh.argtypes = [vp, dp]
+    lib.iqhip_fetch_partial.argtypes = [vp, C.c_uint64, dp]
+    lib.iqhip_fetch_theta.argtypes = [vp, dp]
+    lib.iqhip_upload_partial.argtypes = [vp, C.c_uint64, dp, ip]
+    lib.iqhip_timing_enable.argtypes = [vp, C.c_int]
+    lib.iqhip_timing_read.argtypes = [vp, dp, C.POINTER(C.c_int64), C.c_int]
+    lib._iq_typed = True
+    return lib
+
+
+def libiqhost():
+    libiqhip()  # dependency, loaded RTLD_GLOBAL first
+    lib = _load("libiqhost.so")
+    if getattr(lib, "_iq_typed", False):
+        return lib
+    dp, vp = C.POINTER(C.c_double), C.c_void_p
+    lib.iqhost_last_error.restype = C.c_char_p
+    lib.iqhost_create.argtypes = [C.POINTER(vp), C.c_char_p, C.POINTER(C.c_char_p), C.c_int]
+    lib.iqhost_destroy.argtypes = [vp]
+    lib.iqhost_destroy.restype = None
+    lib.iqhost_set_alignment.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_uint8), dp, dp]
+    lib.iqhost_set_model.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp]
+    lib.iqhost_set_mem_mode.argtypes = [vp, C.c_int]
+    lib.iqhost_set_kernel.argtypes = [vp, C.c_int]
+    lib.iqhost_attach_engine.argtypes = [vp, C.c_int]
+    lib.iqhost_set_dry_run.argtypes = [vp, C.c_int]
+    lib.iqhost_engine.argtypes = [vp]
+    lib.iqhost_engine.restype = vp
+    lib.iqhost_set_allreduce_hook.argtypes = [vp, ALLREDUCE_HOOK, vp]
+    for f in ("iqhost_num_nodes", "iqhost_num_leaves", "iqhost_root", "iqhost_state_unknown"):
+        getattr(lib, f).argtypes = [vp]
+    lib.iqhost_tip_partial_lh.argtypes = [vp, dp]
+    lib.iqhost_neighbors.argtypes = [vp, C.c_int, C.POINTER(C.c_int), dp, C.c_int]
+    lib.iqhost_set_branch_length.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int]
+    lib.iqhost_neighbor_info.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                         C.POINTER(C.c_uint64), dp, dp]
+    lib.iqhost_initialize_all_partial_lh.argtypes = [vp]
+    lib.iqhost_clear_all_partial_lh.argtypes = [vp]
+    lib.iqhost_compute_likelihood.argtypes = [vp, dp, dp]
+    lib.iqhost_current_branch.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.iqhost_compute_partial.argtypes = [vp, C.c_int, C.c_int]
+    lib.iqhost_compute_branch.argtypes = [vp, C.c_int, C.c_int, dp]
+    lib.iqhost_compute_derv.argtypes = [vp, C.c_int, C.c_int, dp, dp]
+    lib.iqhost_reset_theta.argtypes = [vp]
+    lib.iqhost_compute_from_buffer.argtypes = [vp, dp]
+    lib.iqhost_optimize_one_branch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+    lib.iqhost_optimize_all_branches.argtypes = [vp, C.c_int, C.c_double, C.c_int, dp]
+    lib.iqhost_set_branch_bounds.argtypes = [vp, C.c_double, C.c_double]
+    lib.iqhost_tree_string.argtypes = [vp, C.c_char_p, C.c_int]
+    lib.iqhost_fetch_scale_num.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int16)]
+    lib.iqhost_fetch_partial.argtypes = [vp, C.c_int, C.c_int, dp]
+    lib.iqhost_fetch_pattern_lh.argtypes = [vp, dp]
+    lib.iqhost_last_plan.argtypes = [vp, C.POINTER(C.c_int), dp, C.POINTER(C.c_uint64), C.c_int]
+    lib.iqhost_num_partial_lh_computations.argtypes = [vp]
+    lib.iqhost_num_partial_lh_computations.restype = C.c_long
+    lib.iqhost_num_submissions.argtypes = [vp]
+    lib.iqhost_num_submissions.restype = C.c_long
+    lib._iq_typed = True
+    return lib
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class HostError(RuntimeError):
+    pass
+
+
+LK_EIGEN, LK_EIGEN_SSE, LK_EIGEN_HIP = 0, 1, 2
+LM_PER_NODE, LM_ALL_BRANCH = 0, 1
+SEQ_DNA, SEQ_PROTEIN, SEQ_CODON, SEQ_OTHER = 0, 1, 2, 3
+
+
+class PhyloTree:
+    """Thin OO view of iqhost::PhyloTree (iq-tree_amd/host/phylo_host.h)."""
+
+    def __init__(self, newick, names=None):
+        self.lib = libiqhost()
+        self.h = C.c_void_p()
+        if names:
+            arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+            rc = self.lib.iqhost_create(C.byref(self.h), newick.encode(), arr, len(names))
+        else:
+            rc = self.lib.iqhost_create(C.byref(self.h), newick.encode(), None, 0)
+        self._chk(rc)
+        self.nptn = 0
+        self.block = 0
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise HostError(self.lib.iqhost_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.lib.iqhost_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- inputs
+    def set_alignment(self, nstates, seq_type, states, ptn_freq, ptn_invar=None):
+        states = np.ascontiguousarray(states, dtype=np.uint8)
+        self.nptn = states.shape[1]
+        self.nstates = nstates
+        f = np.ascontiguousarray(ptn_freq, dtype=np.float64)
+        iv = np.zeros(self.nptn) if ptn_invar is None else np.ascontiguousarray(ptn_invar, dtype=np.float64)
+        self._chk(self.lib.iqhost_set_alignment(self.h, nstates, seq_type, self.nptn,
+                                                states.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                _dptr(f), _dptr(iv)))
+
+    def set_model(self, model):
+        """model: object with eval, evec, inv_evec, rates, props (see synth.Model)."""
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in
+             (model.eval, model.evec, model.inv_evec, model.rates, model.props)]
+        self.ncat = len(a[3])
+        self.block = self.nstates * self.ncat
+        self._chk(self.lib.iqhost_set_model(self.h, self.ncat, *[_dptr(x) for x in a]))
+
+    def set_mem_mode(self, lm):
+        self._chk(self.lib.iqhost_set_mem_mode(self.h, lm))
+
+    def set_likelihood_kernel(self, lk):
+        self._chk(self.lib.iqhost_set_kernel(self.h, lk))
+
+    def attach_engine(self, device=0):
+        self._chk(self.lib.iqhost_attach_engine(self.h, device))
+
+    def set_dry_run(self, on=True):
+        self._chk(self.lib.iqhost_set_dry_run(self.h, int(on)))
+
+    @property
+    def engine(self):
+        return self.lib.iqhost_engine(self.h)
+
+    def set_allreduce_hook(self, fn):
+        """fn(device_ptr:int, ndoubles:int) all-reduces the device result vector in place."""
+        if fn is None:
+            self._hook = None
+            self._chk(self.lib.iqhost_set_allreduce_hook(self.h, ALLREDUCE_HOOK(0), None))
+            return
+        self._hook = ALLREDUCE_HOOK(lambda ptr, n, ctx: fn(ptr, n))
+        self._chk(self.lib.iqhost_set_allreduce_hook(self.h, self._hook, None))
+
+    # ---- structure
+    @property
+    def num_nodes(self):
+        return self.lib.iqhost_num_nodes(self.h)
+
+    @property
+    def num_leaves(self):
+        return self.lib.iqhost_num_leaves(self.h)
+
+    @property
+    def root(self):
+        return self.lib.iqhost_root(self.h)
+
+    @property
+    def state_unknown(self):
+        return self.lib.iqhost_state_unknown(self.h)
+
+    def tip_partial_lh(self):
+        out = np.zeros((self.state_unknown + 1) * self.nstates)
+        self.lib.iqhost_tip_partial_lh(self.h, _dptr(out))
+        return out.reshape(self.state_unknown + 1, self.nstates)
+
+    def neighbors(self, node):
+        ids = (C.c_int * 8)()
+        lens = (C.c_double * 8)()
+        d = self.lib.iqhost_neighbors(self.h, node, ids, lens, 8)
+        return [(ids[i], lens[i]) for i in range(d)]
+
+    def set_branch_length(self, a, b, length, clear_reverse=True):
+        self._chk(self.lib.iqhost_set_branch_length(self.h, a, b, length, int(clear_reverse)))
+
+    def neighbor_info(self, frm, to):
+        comp, key = C.c_int(), C.c_uint64()
+        sf, ln = C.c_double(), C.c_double()
+        self._chk(self.lib.iqhost_neighbor_info(self.h, frm, to, C.byref(comp), C.byref(key),
+                                                C.byref(sf), C.byref(ln)))
+        return dict(computed=comp.value, key=key.value, lh_scale_factor=sf.value, length=ln.value)
+
+    def tree_string(self):
+        buf = C.create_string_buffer(1 << 20)
+        self.lib.iqhost_tree_string(self.h, buf, len(buf))
+        return buf.value.decode()
+
+    # ---- the reference's call sequence
+    def initialize_all_partial_lh(self):
+        self._chk(self.lib.iqhost_initialize_all_partial_lh(self.h))
+
+    def clear_all_partial_lh(self):
+        self._chk(self.lib.iqhost_clear_all_partial_lh(self.h))
+
+    def compute_likelihood(self, want_pattern_lh=False):
+        lnl = C.c_double()
+        if want_pattern_lh:
+            plh = np.zeros(self.nptn)
+            self._chk(self.lib.iqhost_compute_likelihood(self.h, C.byref(lnl), _dptr(plh)))
+            return lnl.value, plh
+        self._chk(self.lib.iqhost_compute_likelihood(self.h, C.byref(lnl), None))
+        return lnl.value
+
+    def current_branch(self):
+        a, b = C.c_int(), C.c_int()
+        if self.lib.iqhost_current_branch(self.h, C.byref(a), C.byref(b)):
+            return None
+        return a.value, b.value
+
+    def compute_partial_likelihood(self, dad, node):
+        self._chk(self.lib.iqhost_compute_partial(self.h, dad, node))
+
+    def compute_likelihood_branch(self, dad, node):
+        lnl = C.c_double()
+        self._chk(self.lib.iqhost_compute_branch(self.h, dad, node, C.byref(lnl)))
+        return lnl.value
+
+    def compute_likelihood_derv(self, dad, node):
+        df, ddf = C.c_double(), C.c_double()
+        self._chk(self.lib.iqhost_compute_derv(self.h, dad, node, C.byref(df), C.byref(ddf)))
+        return df.value, ddf.value
+
+    def reset_theta(self):
+        self._chk(self.lib.iqhost_reset_theta(self.h))
+
+    def compute_likelihood_from_buffer(self):
+        lnl = C.c_double()
+        self._chk(self.lib.iqhost_compute_from_buffer(self.h, C.byref(lnl)))
+        return lnl.value
+
+    def optimize_one_branch(self, a, b, clear_lh=True, max_nr_step=100):
+        ln = C.c_double()
+        self._chk(self.lib.iqhost_optimize_one_branch(self.h, a, b, int(clear_lh), max_nr_step, C.byref(ln)))
+        return ln.value
+
+    def optimize_all_branches(self, iterations=100, tolerance=0.001, max_nr_step=100):
+        lnl = C.c_double()
+        self._chk(self.lib.iqhost_optimize_all_branches(self.h, iterations, tolerance, max_nr_step, C.byref(lnl)))
+        return lnl.value
+
+    def set_branch_bounds(self, lo, hi):
+        self._chk(self.lib.iqhost_set_branch_bounds(self.h, lo, hi))
+
+    # ---- host views
+    def fetch_scale_num(self, frm, to):
+        out = np.zeros(self.nptn, dtype=np.int16)
+        self._chk(self.lib.iqhost_fetch_scale_num(self.h, frm, to, out.ctypes.data_as(C.POINTER(C.c_int16))))
+        return out
+
+    def fetch_partial(self, frm, to):
+        out = np.zeros(self.nptn * self.block)
+        self._chk(self.lib.iqhost_fetch_partial(self.h, frm, to, _dptr(out)))
+        return out.reshape(self.nptn, self.block)
+
+    def fetch_pattern_lh(self):
+        out = np.zeros(self.nptn)
+        self._chk(self.lib.iqhost_fetch_pattern_lh(self.h, _dptr(out)))
+        return out
+
+    def last_plan(self):
+        cap = 4 * self.num_nodes + 8
+        ints = (C.c_int * (7 * cap))()
+        lens = (C.c_double * (2 * cap))()
+        keys = (C.c_uint64 * (3 * cap))()
+        n = self.lib.iqhost_last_plan(self.h, ints, lens, keys, cap)
+        plan = []
+        for k in range(n):
+            plan.append(dict(dst=(ints[7 * k], ints[7 * k + 1]), left=ints[7 * k + 2], right=ints[7 * k + 3],
+                             left_leaf=ints[7 * k + 4], right_leaf=ints[7 * k + 5],
+                             left_len=lens[2 * k], right_len=lens[2 * k + 1],
+                             dst_key=keys[3 * k], left_key=keys[3 * k + 1], right_key=keys[3 * k + 2]))
+        return plan
+
+    @property
+    def num_partial_lh_computations(self):
+        return self.lib.iqhost_num_partial_lh_computations(self.h)
+
+    @property
+    def num_submissions(self):
+        return self.lib.iqhost_num_submissions(self.h)

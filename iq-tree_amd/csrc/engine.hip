@@ -1,0 +1,699 @@
+// engine.hip -- host side of libiqhip.so: device memory, key->slab map, plan building and the
+// extern "C" entry points declared in include/iqhip.h.  There is NO CPU fallback in this
+// library: every compute entry point launches HIP kernels or fails with a status.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "iqhip_internal.h"
+
+using namespace iqhip;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(call)                                                                  \
+    do {                                                                              \
+        hipError_t _s = (call);                                                       \
+        if (_s != hipSuccess)                                                         \
+            return fail(IQHIP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_s)); \
+    } while (0)
+
+extern "C" const char *iqhip_last_error(void) { return g_err.c_str(); }
+extern "C" int iqhip_abi_version(void) { return IQHIP_ABI_VERSION; }
+extern "C" int iqhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+template <typename T>
+static hipError_t dmalloc(T **p, size_t count) {
+    return hipMalloc((void **)p, count * sizeof(T));
+}
+
+extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int ncat, int64_t nptn,
+                            int ntaxa) {
+    if (!out) return fail(IQHIP_ERR_INVALID, "iqhip_create: out == NULL");
+    *out = nullptr;
+    if (nptn <= 0 || ntaxa < 2 || ncat < 1)
+        return fail(IQHIP_ERR_INVALID, "iqhip_create: bad nptn/ntaxa/ncat");
+    if (nstates != 4)
+        return fail(IQHIP_ERR_UNSUPPORTED,
+                    "iqhip_create: nstates must be 4 in this build (20/64 MFMA path pending)");
+    if (!(ncat >= 1 && ncat <= 8 && ncat != 7))
+        return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_create: ncat must be in {1..6,8}");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(IQHIP_ERR_NO_DEVICE, "iqhip_create: no HIP device available");
+    if (device < 0 || device >= ndev) return fail(IQHIP_ERR_INVALID, "iqhip_create: bad device id");
+    HIPCHK(hipSetDevice(device));
+
+    iqhip_engine *e = new iqhip_engine();
+    e->device = device;
+    e->n = nstates;
+    e->ncat = ncat;
+    e->ntaxa = ntaxa;
+    e->nptn = nptn;
+    e->tile = 64;
+    e->block = nstates * ncat;
+    e->nptn_pad = round_up(nptn, e->tile);
+    e->ntiles = e->nptn_pad / e->tile;
+
+    hipError_t s = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (s != hipSuccess) {
+        delete e;
+        return fail(IQHIP_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(s));
+    }
+    e->own_stream = true;
+
+    const size_t P = (size_t)e->nptn_pad;
+    bool ok = dmalloc(&e->d_states, (size_t)ntaxa * P) == hipSuccess &&
+              dmalloc(&e->d_freq, P) == hipSuccess && dmalloc(&e->d_invar, P) == hipSuccess &&
+              dmalloc(&e->d_eval, nstates) == hipSuccess &&
+              dmalloc(&e->d_evec, nstates * nstates) == hipSuccess &&
+              dmalloc(&e->d_inv_evec, nstates * nstates) == hipSuccess &&
+              dmalloc(&e->d_rates, ncat) == hipSuccess && dmalloc(&e->d_props, ncat) == hipSuccess &&
+              dmalloc(&e->d_tip, 256 * (size_t)nstates) == hipSuccess &&
+              dmalloc(&e->d_theta, P * e->block) == hipSuccess &&
+              dmalloc(&e->d_pattern_lh, P) == hipSuccess;
+    e->result_cap = 2 + 4096;
+    ok = ok && dmalloc(&e->d_result_own, e->result_cap) == hipSuccess &&
+         hipHostMalloc((void **)&e->h_result, e->result_cap * sizeof(double)) == hipSuccess &&
+         hipEventCreateWithFlags(&e->staging_free, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        iqhip_destroy(e);
+        return fail(IQHIP_ERR_NOMEM, "iqhip_create: device allocation failed");
+    }
+    e->d_result = e->d_result_own;
+    hipMemsetAsync(e->d_theta, 0, P * e->block * sizeof(double), e->stream);
+    hipMemsetAsync(e->d_pattern_lh, 0, P * sizeof(double), e->stream);
+    hipMemsetAsync(e->d_result_own, 0, e->result_cap * sizeof(double), e->stream);
+    hipStreamSynchronize(e->stream);
+    *out = e;
+    return IQHIP_OK;
+}
+
+extern "C" void iqhip_destroy(iqhip_engine *e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    for (auto &s : e->slabs) {
+        if (s.plh) hipFree(s.plh);
+        if (s.sc) hipFree(s.sc);
+    }
+    void *ptrs[] = {e->d_states, e->d_freq, e->d_invar, e->d_eval, e->d_evec, e->d_inv_evec,
+                    e->d_rates, e->d_props, e->d_tip, e->d_ops, e->d_opmat, e->d_val, e->d_slab,
+                    e->d_theta, e->d_pattern_lh, e->d_result_own};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    if (e->h_ops) hipHostFree(e->h_ops);
+    if (e->h_result) hipHostFree(e->h_result);
+    if (e->staging_free) hipEventDestroy(e->staging_free);
+    for (auto &p : e->tev) {
+        hipEventDestroy(p.first);
+        hipEventDestroy(p.second);
+    }
+    if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" int iqhip_set_stream(iqhip_engine *e, void *hip_stream) {
+    if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->own_stream) hipStreamDestroy(e->stream);
+    e->stream = (hipStream_t)hip_stream;
+    e->own_stream = false;
+    return IQHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// slabs
+// ---------------------------------------------------------------------------------------
+static int new_slab(iqhip_engine *e, int *idx) {
+    if (!e->free_slabs.empty()) {
+        *idx = e->free_slabs.back();
+        e->free_slabs.pop_back();
+        return IQHIP_OK;
+    }
+    Slab s;
+    const size_t P = (size_t)e->nptn_pad;
+    if (dmalloc(&s.plh, P * e->block) != hipSuccess) return fail(IQHIP_ERR_NOMEM, "slab alloc");
+    if (dmalloc(&s.sc, P) != hipSuccess) {
+        hipFree(s.plh);
+        return fail(IQHIP_ERR_NOMEM, "slab alloc");
+    }
+    // padded lanes must hold finite values from the start
+    hipMemsetAsync(s.plh, 0, P * e->block * sizeof(double), e->stream);
+    hipMemsetAsync(s.sc, 0, P * sizeof(int16_t), e->stream);
+    e->slabs.push_back(s);
+    *idx = (int)e->slabs.size() - 1;
+    return IQHIP_OK;
+}
+
+static int slab_for_key(iqhip_engine *e, uint64_t key, bool create, int *idx) {
+    auto it = e->key2slab.find(key);
+    if (it != e->key2slab.end()) {
+        *idx = it->second;
+        return IQHIP_OK;
+    }
+    if (!create) return fail(IQHIP_ERR_INVALID, "unknown partial_lh key (vector never computed)");
+    int rc = new_slab(e, idx);
+    if (rc) return rc;
+    e->key2slab[key] = *idx;
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_reserve(iqhip_engine *e, int nvectors) {
+    if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    HIPCHK(hipSetDevice(e->device));
+    int have = (int)e->slabs.size();
+    for (int i = have; i < nvectors; i++) {
+        int idx;
+        // temporarily empty the free list so that new_slab really allocates
+        std::vector<int> keep;
+        keep.swap(e->free_slabs);
+        int rc = new_slab(e, &idx);
+        keep.swap(e->free_slabs);
+        if (rc) return rc;
+        e->free_slabs.push_back(idx);
+    }
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_release(iqhip_engine *e, uint64_t key) {
+    if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    auto it = e->key2slab.find(key);
+    if (it == e->key2slab.end()) return IQHIP_OK;
+    e->free_slabs.push_back(it->second);
+    e->key2slab.erase(it);
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_rekey(iqhip_engine *e, uint64_t old_key, uint64_t new_key) {
+    if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    auto it = e->key2slab.find(old_key);
+    if (it == e->key2slab.end()) return fail(IQHIP_ERR_INVALID, "iqhip_rekey: unknown key");
+    if (old_key == new_key) return IQHIP_OK;
+    if (e->key2slab.count(new_key)) iqhip_release(e, new_key);
+    int idx = it->second;
+    e->key2slab.erase(it);
+    e->key2slab[new_key] = idx;
+    return IQHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// inputs
+// ---------------------------------------------------------------------------------------
+extern "C" int iqhip_set_ptn_freq(iqhip_engine *e, const double *ptn_freq) {
+    if (!e || !ptn_freq) return fail(IQHIP_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<double> tmp((size_t)e->nptn_pad, 0.0);
+    memcpy(tmp.data(), ptn_freq, sizeof(double) * (size_t)e->nptn);
+    HIPCHK(hipMemcpyAsync(e->d_freq, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice,
+                          e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_set_ptn_invar(iqhip_engine *e, const double *ptn_invar) {
+    if (!e || !ptn_invar) return fail(IQHIP_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<double> tmp((size_t)e->nptn_pad, 0.0);
+    memcpy(tmp.data(), ptn_invar, sizeof(double) * (size_t)e->nptn);
+    HIPCHK(hipMemcpyAsync(e->d_invar, tmp.data(), tmp.size() * sizeof(double),
+                          hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_set_alignment(iqhip_engine *e, const uint8_t *states, const double *ptn_freq,
+                                   const double *ptn_invar) {
+    if (!e || !states || !ptn_freq || !ptn_invar) return fail(IQHIP_ERR_INVALID, "null argument");
+    if (!e->model_set)
+        return fail(IQHIP_ERR_INVALID,
+                    "iqhip_set_alignment: call iqhip_set_model first (needs state_unknown)");
+    HIPCHK(hipSetDevice(e->device));
+    const size_t P = (size_t)e->nptn_pad, N = (size_t)e->nptn;
+    std::vector<uint8_t> tmp((size_t)e->ntaxa * P, (uint8_t)e->state_unknown);
+    for (int t = 0; t < e->ntaxa; t++) {
+        const uint8_t *src = states + (size_t)t * N;
+        for (size_t p = 0; p < N; p++)
+            if (src[p] > e->state_unknown)
+                return fail(IQHIP_ERR_INVALID, "iqhip_set_alignment: state > STATE_UNKNOWN");
+        memcpy(tmp.data() + (size_t)t * P, src, N);
+    }
+    HIPCHK(hipMemcpyAsync(e->d_states, tmp.data(), tmp.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int rc = iqhip_set_ptn_freq(e, ptn_freq);
+    if (rc) return rc;
+    rc = iqhip_set_ptn_invar(e, ptn_invar);
+    if (rc) return rc;
+    e->aln_set = true;
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_set_model(iqhip_engine *e, const double *eval, const double *evec,
+                               const double *inv_evec, const double *rates, const double *props,
+                               int state_unknown, const double *tip_partial_lh) {
+    if (!e || !eval || !evec || !inv_evec || !rates || !props || !tip_partial_lh)
+        return fail(IQHIP_ERR_INVALID, "null argument");
+    if (state_unknown < e->n || state_unknown > 31)
+        return fail(IQHIP_ERR_INVALID, "iqhip_set_model: state_unknown out of range");
+    if (e->aln_set && state_unknown != e->state_unknown)
+        return fail(IQHIP_ERR_INVALID, "iqhip_set_model: state_unknown changed after set_alignment");
+    HIPCHK(hipSetDevice(e->device));
+    const int n = e->n;
+    HIPCHK(hipStreamSynchronize(e->stream));  // previous work may still read the old model
+    HIPCHK(hipMemcpy(e->d_eval, eval, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_evec, evec, sizeof(double) * n * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_inv_evec, inv_evec, sizeof(double) * n * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_rates, rates, sizeof(double) * e->ncat, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_props, props, sizeof(double) * e->ncat, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_tip, tip_partial_lh, sizeof(double) * (state_unknown + 1) * n,
+                     hipMemcpyHostToDevice));
+    e->state_unknown = state_unknown;
+    e->model_set = true;
+    e->theta_valid = false;
+    return IQHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// plan building
+// ---------------------------------------------------------------------------------------
+static int ensure_plan_capacity(iqhip_engine *e, int nops) {
+    if (nops > e->result_cap - 2)
+        return fail(IQHIP_ERR_INVALID, "too many node updates in one submission");
+    if (nops <= e->ops_cap) return IQHIP_OK;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int cap = std::max(64, nops * 2);
+    if (e->d_ops) hipFree(e->d_ops);
+    if (e->d_opmat) hipFree(e->d_opmat);
+    if (e->h_ops) hipHostFree(e->h_ops);
+    e->d_ops = nullptr; e->d_opmat = nullptr; e->h_ops = nullptr; e->ops_cap = 0;
+    HIPCHK(dmalloc(&e->d_ops, cap));
+    HIPCHK(dmalloc(&e->d_opmat, (size_t)cap * 2 * e->ncat * e->n * e->n));
+    HIPCHK(hipHostMalloc((void **)&e->h_ops, sizeof(DevOp) * cap));
+    e->ops_cap = cap;
+    return IQHIP_OK;
+}
+
+static int ensure_slab_rows(iqhip_engine *e, int nrows) {
+    const int64_t need = (int64_t)nrows * e->ntiles;
+    if (need <= e->slab_cap) return IQHIP_OK;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->d_slab) hipFree(e->d_slab);
+    e->d_slab = nullptr;
+    e->slab_cap = 0;
+    HIPCHK(dmalloc(&e->d_slab, (size_t)need));
+    e->slab_cap = need;
+    return IQHIP_OK;
+}
+
+static int check_ready(iqhip_engine *e) {
+    if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    if (!e->model_set || !e->aln_set)
+        return fail(IQHIP_ERR_INVALID, "engine needs iqhip_set_model and iqhip_set_alignment first");
+    hipError_t s = hipSetDevice(e->device);
+    if (s != hipSuccess) return fail(IQHIP_ERR_HIP, hipGetErrorString(s));
+    return IQHIP_OK;
+}
+
+// Resolve one child of a node op. prev_dst = slab index written by the previous op (-1: none).
+static int resolve_child(iqhip_engine *e, uint64_t key, int32_t leaf, int prev_dst,
+                         const double **plh, const int16_t **sc, const uint8_t **states,
+                         int32_t *kind) {
+    *plh = nullptr; *sc = nullptr; *states = nullptr;
+    if (leaf >= 0) {
+        if (leaf >= e->ntaxa) return fail(IQHIP_ERR_INVALID, "leaf id out of range");
+        *states = e->d_states + (size_t)leaf * e->nptn_pad;
+        *kind = CHILD_LEAF;
+        return IQHIP_OK;
+    }
+    int idx;
+    int rc = slab_for_key(e, key, false, &idx);
+    if (rc) return rc;
+    *plh = e->slabs[idx].plh;
+    *sc = e->slabs[idx].sc;
+    *kind = (idx == prev_dst) ? CHILD_PREV : CHILD_LOAD;
+    return IQHIP_OK;
+}
+
+static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *last_dst) {
+    int rc = ensure_plan_capacity(e, nops);
+    if (rc) return rc;
+    if (e->staging_busy) {  // the previous submission may still be copying h_ops
+        HIPCHK(hipEventSynchronize(e->staging_free));
+        e->staging_busy = false;
+    }
+    int prev_dst = -1;
+    for (int k = 0; k < nops; k++) {
+        const iqhip_node_op &o = ops[k];
+        DevOp &d = e->h_ops[k];
+        if (!(o.left_len >= 0.0) || !(o.right_len >= 0.0))
+            return fail(IQHIP_ERR_INVALID, "negative or NaN branch length");
+        rc = resolve_child(e, o.left_key, o.left_leaf, prev_dst, &d.left, &d.left_sc, &d.left_states,
+                           &d.left_kind);
+        if (rc) return rc;
+        rc = resolve_child(e, o.right_key, o.right_leaf, prev_dst, &d.right, &d.right_sc,
+                           &d.right_states, &d.right_kind);
+        if (rc) return rc;
+        int didx;
+        rc = slab_for_key(e, o.dst_key, true, &didx);
+        if (rc) return rc;
+        if ((d.left_kind != CHILD_LEAF && d.left == e->slabs[didx].plh) ||
+            (d.right_kind != CHILD_LEAF && d.right == e->slabs[didx].plh))
+            return fail(IQHIP_ERR_INVALID, "node update writes onto one of its own children");
+        d.dst = e->slabs[didx].plh;
+        d.dst_sc = e->slabs[didx].sc;
+        d.left_len = o.left_len;
+        d.right_len = o.right_len;
+        prev_dst = didx;
+    }
+    *last_dst = prev_dst;
+    if (nops > 0) {
+        HIPCHK(hipMemcpyAsync(e->d_ops, e->h_ops, sizeof(DevOp) * nops, hipMemcpyHostToDevice,
+                              e->stream));
+        HIPCHK(hipEventRecord(e->staging_free, e->stream));
+        e->staging_busy = true;
+    }
+    return IQHIP_OK;
+}
+
+static int build_branch(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b, double len,
+                        int prev_dst, DevBranch *br) {
+    if (!(len >= 0.0)) return fail(IQHIP_ERR_INVALID, "negative or NaN branch length");
+    if (a.leaf >= 0 && b.leaf >= 0)
+        return fail(IQHIP_ERR_INVALID, "branch with two leaf ends (2-taxon tree) is not supported");
+    if (b.leaf >= 0) std::swap(a, b);  // the reference puts the leaf on the `dad` side (:739-746)
+    const int16_t *sc_unused;
+    const uint8_t *st_unused;
+    int rc = resolve_child(e, a.key, a.leaf, prev_dst, &br->a, &sc_unused, &br->a_states, &br->a_kind);
+    if (rc) return rc;
+    rc = resolve_child(e, b.key, b.leaf, prev_dst, &br->b, &sc_unused, &st_unused, &br->b_kind);
+    if (rc) return rc;
+    br->len = len;
+    return IQHIP_OK;
+}
+
+static void timing_begin(iqhip_engine *e) {
+    if (!e->timing) return;
+    if (e->tev_used == e->tev.size()) {
+        hipEvent_t a, b;
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        e->tev.emplace_back(a, b);
+    }
+    hipEventRecord(e->tev[e->tev_used].first, e->stream);
+}
+static void timing_end(iqhip_engine *e) {
+    if (!e->timing) return;
+    hipEventRecord(e->tev[e->tev_used].second, e->stream);
+    e->tev_used++;
+}
+
+// enqueue: plan upload, K1, fused traversal (+ optional root lnL), fixed-order reduction
+static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, bool has_root,
+                           iqhip_branch_end a, iqhip_branch_end b, double len) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    if (nops < 0 || (nops > 0 && !ops)) return fail(IQHIP_ERR_INVALID, "bad ops array");
+    int last_dst = -1;
+    rc = build_plan(e, ops, nops, &last_dst);
+    if (rc) return rc;
+    DevBranch br;
+    if (has_root) {
+        rc = build_branch(e, a, b, len, last_dst, &br);
+        if (rc) return rc;
+    }
+    rc = ensure_slab_rows(e, 2 + nops);
+    if (rc) return rc;
+    const int nwaves = (int)e->ntiles;
+    HIPCHK(launch_echild(e, nops));
+    timing_begin(e);
+    HIPCHK(launch_traverse4(e, nops, has_root ? &br : nullptr, nwaves));
+    timing_end(e);
+    if (has_root) HIPCHK(launch_reduce(e, 0, 2 + nops, nwaves));
+    else HIPCHK(launch_reduce(e, 2, nops, nwaves));
+    e->last_nops = nops;
+    return IQHIP_OK;
+}
+
+static int read_result(iqhip_engine *e, int ndoubles) {
+    HIPCHK(hipMemcpyAsync(e->h_result, e->d_result, sizeof(double) * ndoubles, hipMemcpyDeviceToHost,
+                          e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->staging_busy = false;
+    return IQHIP_OK;
+}
+
+// the NaN/Inf repair of phylokernel.h:848-866 / :1100-1122, done on the (rare) slow path
+static int repair_lnl(iqhip_engine *e, double *lnl) {
+    std::vector<double> plh((size_t)e->nptn_pad), freq((size_t)e->nptn_pad);
+    HIPCHK(hipMemcpy(plh.data(), e->d_pattern_lh, sizeof(double) * plh.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(freq.data(), e->d_freq, sizeof(double) * freq.size(), hipMemcpyDeviceToHost));
+    double s = 0.0;
+    for (int64_t p = 0; p < e->nptn; p++) {
+        if (isnan(plh[p]) || isinf(plh[p])) plh[p] = kLogScalingThreshold * 4;
+        s += plh[p] * freq[p];
+    }
+    HIPCHK(hipMemcpy(e->d_pattern_lh, plh.data(), sizeof(double) * plh.size(), hipMemcpyHostToDevice));
+    *lnl = s;
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_update_partials(iqhip_engine *e, const iqhip_node_op *ops, int nops,
+                                     double *sum_scale) {
+    iqhip_branch_end none = {0, -1, 0};
+    int rc = submit_traverse(e, ops, nops, false, none, none, 0.0);
+    if (rc) return rc;
+    rc = read_result(e, 2 + nops);
+    if (rc) return rc;
+    if (sum_scale)
+        for (int k = 0; k < nops; k++) sum_scale[k] = e->h_result[2 + k];
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_traverse_lnl(iqhip_engine *e, const iqhip_node_op *ops, int nops,
+                                  iqhip_branch_end a, iqhip_branch_end b, double len,
+                                  double *sum_scale, double *lnl) {
+    int rc = submit_traverse(e, ops, nops, true, a, b, len);
+    if (rc) return rc;
+    rc = read_result(e, 2 + nops);
+    if (rc) return rc;
+    if (sum_scale)
+        for (int k = 0; k < nops; k++) sum_scale[k] = e->h_result[2 + k];
+    double v = e->h_result[0];
+    if (isnan(v) || isinf(v)) {
+        rc = repair_lnl(e, &v);
+        if (rc) return rc;
+    }
+    if (lnl) *lnl = v;
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_branch_lnl(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b, double len,
+                                double *lnl) {
+    return iqhip_traverse_lnl(e, nullptr, 0, a, b, len, nullptr, lnl);
+}
+
+extern "C" int iqhip_traverse_lnl_async(iqhip_engine *e, const iqhip_node_op *ops, int nops,
+                                        iqhip_branch_end a, iqhip_branch_end b, double len) {
+    return submit_traverse(e, ops, nops, true, a, b, len);
+}
+
+extern "C" int iqhip_compute_theta(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    DevBranch br;
+    rc = build_branch(e, a, b, 0.0, -1, &br);
+    if (rc) return rc;
+    HIPCHK(launch_theta4(e, br));
+    e->theta_valid = true;
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_derv_async(iqhip_engine *e, double len) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    if (!e->theta_valid) return fail(IQHIP_ERR_INVALID, "iqhip_derv: theta not computed");
+    if (!(len >= 0.0)) return fail(IQHIP_ERR_INVALID, "negative or NaN branch length");
+    rc = ensure_slab_rows(e, 2);
+    if (rc) return rc;
+    const int nwaves = (int)e->ntiles;
+    HIPCHK(launch_derv4(e, len, nwaves));
+    HIPCHK(launch_reduce(e, 0, 2, nwaves));
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_derv(iqhip_engine *e, double len, double *df, double *ddf) {
+    int rc = iqhip_derv_async(e, len);
+    if (rc) return rc;
+    rc = read_result(e, 2);
+    if (rc) return rc;
+    double a = e->h_result[0], b = e->h_result[1];
+    if (isnan(a) || isinf(a)) { a = 0.0; b = 0.0; }  // phylokernel.h:647-651
+    if (df) *df = a;
+    if (ddf) *ddf = b;
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_lnl_from_theta(iqhip_engine *e, double len, double *lnl) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    if (!e->theta_valid) return fail(IQHIP_ERR_INVALID, "iqhip_lnl_from_theta: theta not computed");
+    if (!(len >= 0.0)) return fail(IQHIP_ERR_INVALID, "negative or NaN branch length");
+    rc = ensure_slab_rows(e, 2);
+    if (rc) return rc;
+    const int nwaves = (int)e->ntiles;
+    HIPCHK(launch_lnl_theta4(e, len, nwaves));
+    HIPCHK(launch_reduce(e, 0, 1, nwaves));
+    rc = read_result(e, 1);
+    if (rc) return rc;
+    double v = e->h_result[0];
+    if (isnan(v) || isinf(v)) {
+        rc = repair_lnl(e, &v);
+        if (rc) return rc;
+    }
+    if (lnl) *lnl = v;
+    return IQHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// result buffer / sync
+// ---------------------------------------------------------------------------------------
+extern "C" int iqhip_bind_result_buffer(iqhip_engine *e, void *device_ptr, int capacity_doubles) {
+    if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (!device_ptr) {
+        e->d_result = e->d_result_own;
+        e->result_cap = 2 + 4096;
+        return IQHIP_OK;
+    }
+    if (capacity_doubles < 2) return fail(IQHIP_ERR_INVALID, "result buffer too small");
+    e->d_result = (double *)device_ptr;
+    e->result_cap = std::min(capacity_doubles, 2 + 4096);
+    return IQHIP_OK;
+}
+extern "C" void *iqhip_result_device_ptr(iqhip_engine *e) { return e ? (void *)e->d_result : nullptr; }
+extern "C" int iqhip_result_capacity(iqhip_engine *e) { return e ? e->result_cap : 0; }
+
+extern "C" int iqhip_result_read(iqhip_engine *e, double *out, int ndoubles) {
+    if (!e || !out || ndoubles < 0 || ndoubles > e->result_cap)
+        return fail(IQHIP_ERR_INVALID, "iqhip_result_read: bad arguments");
+    HIPCHK(hipSetDevice(e->device));
+    int rc = read_result(e, ndoubles);
+    if (rc) return rc;
+    memcpy(out, e->h_result, sizeof(double) * ndoubles);
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_synchronize(iqhip_engine *e) {
+    if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->staging_busy = false;
+    return IQHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// host views (layout conversion on the host; these are off the hot path)
+// ---------------------------------------------------------------------------------------
+static inline size_t dev_index4(int64_t p, int e_, int B) {
+    return (size_t)(p >> 6) * 64 * B + (size_t)(e_ >> 1) * 128 + (size_t)(p & 63) * 2 + (e_ & 1);
+}
+
+static int fetch_vec(iqhip_engine *e, const double *dptr, double *out) {
+    std::vector<double> tmp((size_t)e->nptn_pad * e->block);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(tmp.data(), dptr, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const int B = e->block;
+    for (int64_t p = 0; p < e->nptn; p++)
+        for (int k = 0; k < B; k++) out[(size_t)p * B + k] = tmp[dev_index4(p, k, B)];
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_fetch_partial(iqhip_engine *e, uint64_t key, double *out) {
+    if (!e || !out) return fail(IQHIP_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->device));
+    int idx;
+    int rc = slab_for_key(e, key, false, &idx);
+    if (rc) return rc;
+    return fetch_vec(e, e->slabs[idx].plh, out);
+}
+
+extern "C" int iqhip_fetch_theta(iqhip_engine *e, double *out) {
+    if (!e || !out) return fail(IQHIP_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->device));
+    return fetch_vec(e, e->d_theta, out);
+}
+
+extern "C" int iqhip_fetch_scale_num(iqhip_engine *e, uint64_t key, int16_t *out) {
+    if (!e || !out) return fail(IQHIP_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->device));
+    int idx;
+    int rc = slab_for_key(e, key, false, &idx);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(out, e->slabs[idx].sc, sizeof(int16_t) * (size_t)e->nptn, hipMemcpyDeviceToHost));
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_fetch_pattern_lh(iqhip_engine *e, double *out) {
+    if (!e || !out) return fail(IQHIP_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(out, e->d_pattern_lh, sizeof(double) * (size_t)e->nptn, hipMemcpyDeviceToHost));
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_upload_partial(iqhip_engine *e, uint64_t key, const double *partial_lh,
+                                    const int16_t *scale_num) {
+    if (!e || !partial_lh || !scale_num) return fail(IQHIP_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->device));
+    int idx;
+    int rc = slab_for_key(e, key, true, &idx);
+    if (rc) return rc;
+    const int B = e->block;
+    std::vector<double> tmp((size_t)e->nptn_pad * B, 0.0);
+    for (int64_t p = 0; p < e->nptn; p++)
+        for (int k = 0; k < B; k++) tmp[dev_index4(p, k, B)] = partial_lh[(size_t)p * B + k];
+    std::vector<int16_t> sc((size_t)e->nptn_pad, 0);
+    memcpy(sc.data(), scale_num, sizeof(int16_t) * (size_t)e->nptn);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(e->slabs[idx].plh, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->slabs[idx].sc, sc.data(), sc.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+    return IQHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// timing of the dominant kernel (HIP events on the launch stream)
+// ---------------------------------------------------------------------------------------
+extern "C" int iqhip_timing_enable(iqhip_engine *e, int on) {
+    if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    e->timing = on != 0;
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_timing_read(iqhip_engine *e, double *avg_ms, int64_t *launches, int reset) {
+    if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    double total = 0.0;
+    for (size_t i = 0; i < e->tev_used; i++) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e->tev[i].first, e->tev[i].second));
+        total += ms;
+    }
+    if (avg_ms) *avg_ms = e->tev_used ? total / (double)e->tev_used : 0.0;
+    if (launches) *launches = (int64_t)e->tev_used;
+    if (reset) e->tev_used = 0;
+    return IQHIP_OK;
+}

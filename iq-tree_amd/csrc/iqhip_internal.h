@@ -1,0 +1,121 @@
+// iqhip_internal.h -- engine-private declarations shared by the engine and the kernel files.
+// Device data layout (DESIGN.md "HBM layout"):
+//   VALU path (nstates == 4): patterns are grouped in tiles of 64 (one wavefront); inside a
+//   tile element e (= c*4+i, the reference's block index) of pattern p is stored at
+//       tile*64*B + (e>>1)*128 + (p&63)*2 + (e&1)            [doubles]
+//   so one global_load_dwordx4 per lane reads two consecutive elements and the wave reads
+//   1 KiB contiguous.
+//   MFMA path (nstates == 20 / 64): tiles of 16 patterns, state-major inside the tile:
+//       tile*16*B + (c*n + i)*16 + (p&15)
+//   which is exactly the B-operand / D-result image of v_mfma_f64_16x16x4_f64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "../../include/iqhip.h"
+
+namespace iqhip {
+
+constexpr double kScalingThreshold = 0x1p-256;       // phylotree.h:52
+constexpr double kScalingThresholdInv = 0x1p256;     // phylotree.h:51
+// log(2^-256) as libm returns it (phylotree.h:53)
+constexpr double kLogScalingThreshold = -177.44567822334599;
+
+enum ChildKind : int32_t { CHILD_LEAF = 0, CHILD_LOAD = 1, CHILD_PREV = 2 };
+
+// One node update as the device sees it. 16-byte aligned so that the wave-uniform reads
+// of the descriptor become scalar loads.
+struct __attribute__((aligned(16))) DevOp {
+    double *dst;
+    int16_t *dst_sc;
+    const double *left;
+    const int16_t *left_sc;
+    const uint8_t *left_states;
+    const double *right;
+    const int16_t *right_sc;
+    const uint8_t *right_states;
+    int32_t left_kind;
+    int32_t right_kind;
+    double left_len;
+    double right_len;
+};
+
+// Root branch descriptor for the lnL / theta kernels.
+struct __attribute__((aligned(16))) DevBranch {
+    const double *a;            // internal side A (nullptr when A is a leaf)
+    const uint8_t *a_states;    // leaf side states (nullptr when A is internal)
+    const double *b;            // always internal
+    int32_t a_kind;             // CHILD_LEAF / CHILD_LOAD / CHILD_PREV
+    int32_t b_kind;             // CHILD_LOAD / CHILD_PREV
+    double len;
+};
+
+struct Slab {
+    double *plh = nullptr;
+    int16_t *sc = nullptr;
+};
+
+}  // namespace iqhip
+
+struct iqhip_engine {
+    int device = 0;
+    int n = 0, ncat = 0, ntaxa = 0;
+    int64_t nptn = 0;      // caller-visible patterns
+    int64_t nptn_pad = 0;  // padded to the tile size
+    int64_t ntiles = 0;    // tiles of `tile` patterns
+    int tile = 64;         // 64 (VALU path) or 16 (MFMA path)
+    int block = 0;         // n*ncat
+    int state_unknown = -1;
+    bool model_set = false, aln_set = false, theta_valid = false;
+
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    // alignment side
+    uint8_t *d_states = nullptr;  // [ntaxa][nptn_pad]
+    double *d_freq = nullptr, *d_invar = nullptr;
+    // model side
+    double *d_eval = nullptr, *d_evec = nullptr, *d_inv_evec = nullptr;
+    double *d_rates = nullptr, *d_props = nullptr, *d_tip = nullptr;
+    std::vector<double> h_eval, h_rates, h_props;
+    // per-call buffers
+    iqhip::DevOp *d_ops = nullptr;
+    int ops_cap = 0;
+    double *d_opmat = nullptr;  // [ops_cap][2][ncat][n][n]
+    double *d_val = nullptr;    // 3*block doubles: val0,val1,val2 for branch kernels
+    double *d_slab = nullptr;   // wave partials [nvals][nwaves]
+    int64_t slab_cap = 0;
+    double *d_theta = nullptr, *d_pattern_lh = nullptr;
+    double *d_result_own = nullptr, *d_result = nullptr;
+    int result_cap = 0;
+    // pinned host staging
+    iqhip::DevOp *h_ops = nullptr;
+    double *h_result = nullptr;
+    hipEvent_t staging_free = nullptr;
+    bool staging_busy = false;
+
+    // key -> slab
+    std::unordered_map<uint64_t, int> key2slab;
+    std::vector<iqhip::Slab> slabs;
+    std::vector<int> free_slabs;
+
+    // timing of the dominant kernel
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;
+    size_t tev_used = 0;
+    int last_nops = 0;
+};
+
+namespace iqhip {
+
+// kernels_valu4.hip
+hipError_t launch_echild(iqhip_engine *e, int nops);
+hipError_t launch_traverse4(iqhip_engine *e, int nops, const DevBranch *root, int nwaves);
+hipError_t launch_theta4(iqhip_engine *e, const DevBranch &br);
+hipError_t launch_derv4(iqhip_engine *e, double len, int nwaves);
+hipError_t launch_lnl_theta4(iqhip_engine *e, double len, int nwaves);
+hipError_t launch_reduce(iqhip_engine *e, int first_row, int nrows, int nwaves);
+
+}  // namespace iqhip

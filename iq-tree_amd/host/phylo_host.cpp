@@ -1,0 +1,745 @@
+// phylo_host.cpp -- see phylo_host.h.  Host logic only; all arithmetic on partial-likelihood
+// vectors happens in libiqhip.so.
+#include "phylo_host.h"
+
+#include <assert.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <sstream>
+
+namespace iqhost {
+
+// log(2^-256), phylotree.h:53
+static const double LOG_SCALING_THRESHOLD = log(0x1p-256);
+
+// =========================================================================================
+// flags (phylonode.cpp:15-65)
+// =========================================================================================
+void PhyloNeighbor::clearForwardPartialLh(PhyloNode *dad) {
+    clearPartialLh();
+    for (PhyloNeighbor *nb : node->neighbors)
+        if (nb->node != dad) nb->clearForwardPartialLh(node);
+}
+
+void PhyloNode::clearReversePartialLh(PhyloNode *dad) {
+    for (PhyloNeighbor *nb : neighbors)
+        if (nb->node != dad) {
+            nb->node->findNeighbor(this)->partial_lh_computed = 0;
+            nb->node->clearReversePartialLh(this);
+        }
+}
+
+void PhyloNode::clearAllPartialLh(bool make_null, PhyloNode *dad) {
+    PhyloNeighbor *nei = findNeighbor(dad);
+    nei->partial_lh_computed = 0;
+    if (make_null) nei->partial_lh = 0;
+    nei = dad->findNeighbor(this);
+    nei->partial_lh_computed = 0;
+    if (make_null) nei->partial_lh = 0;
+    for (PhyloNeighbor *nb : neighbors)
+        if (nb->node != dad) nb->node->clearAllPartialLh(make_null, this);
+}
+
+// =========================================================================================
+// tree
+// =========================================================================================
+PhyloTree::PhyloTree() { setLikelihoodKernel(LK_EIGEN_HIP); }
+
+PhyloTree::~PhyloTree() {
+    if (engine) iqhip_destroy(engine);
+    freeTree();
+}
+
+void PhyloTree::freeTree() {
+    for (PhyloNeighbor *nb : all_neighbors) delete nb;
+    for (PhyloNode *n : nodes) delete n;
+    all_neighbors.clear();
+    nodes.clear();
+    root = nullptr;
+    current_it = current_it_back = nullptr;
+}
+
+namespace {
+struct NwkNode {
+    std::string label;
+    double len = 0.0;
+    bool has_len = false;
+    std::vector<NwkNode *> kids;
+    ~NwkNode() { for (NwkNode *k : kids) delete k; }
+};
+
+struct NwkParser {
+    const std::string &s;
+    size_t pos = 0;
+    explicit NwkParser(const std::string &str) : s(str) {}
+    void skip() { while (pos < s.size() && isspace((unsigned char)s[pos])) pos++; }
+    NwkNode *parse() {
+        skip();
+        NwkNode *n = new NwkNode();
+        if (pos < s.size() && s[pos] == '(') {
+            pos++;
+            for (;;) {
+                n->kids.push_back(parse());
+                skip();
+                if (pos >= s.size()) { delete n; throw std::runtime_error("newick: unexpected end"); }
+                if (s[pos] == ',') { pos++; continue; }
+                if (s[pos] == ')') { pos++; break; }
+                delete n;
+                throw std::runtime_error("newick: expected ',' or ')'");
+            }
+        }
+        skip();
+        size_t b = pos;
+        while (pos < s.size() && !strchr(":,();", s[pos]) && !isspace((unsigned char)s[pos])) pos++;
+        n->label = s.substr(b, pos - b);
+        skip();
+        if (pos < s.size() && s[pos] == ':') {
+            pos++;
+            skip();
+            char *end = nullptr;
+            n->len = strtod(s.c_str() + pos, &end);
+            if (end == s.c_str() + pos) { delete n; throw std::runtime_error("newick: bad branch length"); }
+            pos = end - s.c_str();
+            n->has_len = true;
+        }
+        return n;
+    }
+};
+}  // namespace
+
+void PhyloTree::readTreeString(const std::string &newick, const std::vector<std::string> &names) {
+    deleteAllPartialLh();
+    freeTree();
+    NwkParser P(newick);
+    NwkNode *top = P.parse();
+    struct Guard { NwkNode *p; ~Guard() { delete p; } } guard{top};
+
+    // count leaves
+    std::vector<NwkNode *> stack{top};
+    int nleaf = 0;
+    while (!stack.empty()) {
+        NwkNode *n = stack.back();
+        stack.pop_back();
+        if (n->kids.empty()) nleaf++;
+        for (NwkNode *k : n->kids) stack.push_back(k);
+    }
+    if (nleaf < 3) throw std::runtime_error("tree needs at least 3 taxa");
+    if (!names.empty() && (int)names.size() != nleaf)
+        throw std::runtime_error("newick leaf count differs from the number of sequences");
+    leafNum = nleaf;
+    nodes.assign(nleaf, nullptr);
+    int branch_id = 0;
+
+    auto connect = [&](PhyloNode *a, PhyloNode *b, double len) {
+        PhyloNeighbor *ab = new PhyloNeighbor(), *ba = new PhyloNeighbor();
+        ab->node = b; ab->length = len; ab->id = branch_id;
+        ba->node = a; ba->length = len; ba->id = branch_id;
+        branch_id++;
+        a->neighbors.push_back(ab);
+        b->neighbors.push_back(ba);
+        all_neighbors.push_back(ab);
+        all_neighbors.push_back(ba);
+    };
+    auto leaf_id = [&](const std::string &label) -> int {
+        if (names.empty()) {
+            char *end = nullptr;
+            long v = strtol(label.c_str(), &end, 10);
+            if (label.empty() || *end) throw std::runtime_error("leaf label '" + label + "' is not a taxon id");
+            return (int)v;
+        }
+        for (size_t i = 0; i < names.size(); i++)
+            if (names[i] == label) return (int)i;
+        throw std::runtime_error("leaf label '" + label + "' not found in alignment");
+    };
+    // recursive build; returns the PhyloNode of a newick node
+    struct Builder {
+        PhyloTree *t; decltype(connect) &conn; decltype(leaf_id) &lid;
+        PhyloNode *build(NwkNode *n) {
+            PhyloNode *pn = new PhyloNode();
+            if (n->kids.empty()) {
+                int id = lid(n->label);
+                if (id < 0 || id >= t->leafNum || t->nodes[id]) {
+                    delete pn;
+                    throw std::runtime_error("duplicate or out-of-range taxon '" + n->label + "'");
+                }
+                pn->id = id;
+                pn->name = n->label;
+                t->nodes[id] = pn;
+            } else {
+                pn->id = (int)t->nodes.size();
+                pn->name = n->label;
+                t->nodes.push_back(pn);
+                for (NwkNode *k : n->kids) {
+                    PhyloNode *c = build(k);
+                    conn(pn, c, k->len);
+                }
+            }
+            return pn;
+        }
+    } builder{this, connect, leaf_id};
+
+    if (top->kids.size() == 2) {
+        // rooted input: drop the degree-2 root, join its two children by one branch
+        NwkNode *a = top->kids[0], *b = top->kids[1];
+        if (a->kids.empty() && b->kids.empty()) throw std::runtime_error("tree needs at least 3 taxa");
+        PhyloNode *na = builder.build(a), *nb = builder.build(b);
+        connect(na, nb, a->len + b->len);
+    } else {
+        builder.build(top);
+    }
+    for (PhyloNode *n : nodes)
+        if (!n) throw std::runtime_error("a taxon of the alignment is missing from the tree");
+    nodeNum = (int)nodes.size();
+    branchNum = branch_id;
+    for (PhyloNode *n : nodes)
+        if (!n->isLeaf() && n->degree() < 3) throw std::runtime_error("internal node of degree < 3");
+    root = nodes[0];  // the reference roots at the first taxon by default (setRootNode)
+    current_it = current_it_back = nullptr;
+    theta_computed = false;
+}
+
+static void writeNewick(std::ostringstream &os, const PhyloNode *node, const PhyloNode *dad) {
+    if (node->isLeaf() && dad) {
+        os << node->id;
+        return;
+    }
+    os << "(";
+    bool first = true;
+    for (PhyloNeighbor *nb : node->neighbors)
+        if (nb->node != dad) {
+            if (!first) os << ",";
+            first = false;
+            writeNewick(os, nb->node, node);
+            os.precision(17);
+            os << ":" << nb->length;
+        }
+    os << ")";
+}
+
+std::string PhyloTree::getTreeString() const {
+    std::ostringstream os;
+    if (!root) return ";";
+    // print from the internal node next to the root leaf so the output is a trifurcation
+    const PhyloNode *start = root->neighbors[0]->node;
+    writeNewick(os, start, nullptr);
+    os << ";";
+    return os.str();
+}
+
+PhyloNode *PhyloTree::findFarthestLeaf(PhyloNode *node, PhyloNode *dad) {
+    if (!node) node = root;
+    if (dad && node->isLeaf()) {
+        node->height = 0.0;
+        return node;
+    }
+    PhyloNode *res = nullptr;
+    node->height = 0.0;
+    for (PhyloNeighbor *nb : node->neighbors)
+        if (nb->node != dad) {
+            PhyloNode *leaf = findFarthestLeaf(nb->node, node);
+            if (node->height < nb->node->height + 1) {
+                node->height = nb->node->height + 1;
+                res = leaf;
+            }
+        }
+    return res;
+}
+
+// =========================================================================================
+// inputs
+// =========================================================================================
+void PhyloTree::setAlignment(int nstates, SeqType st, int64_t nptn_, const uint8_t *states,
+                             const double *freq, const double *invar) {
+    if (engine) throw std::runtime_error("setAlignment after attachEngine is not supported");
+    if (leafNum <= 0) throw std::runtime_error("readTreeString first");
+    num_states = nstates;
+    seq_type = st;
+    nptn = nptn_;
+    // alignment.cpp:470-472
+    STATE_UNKNOWN = (st == SEQ_DNA && nstates == 4) ? 18 : (st == SEQ_PROTEIN && nstates == 20) ? 23 : nstates;
+    aln_states.assign(states, states + (size_t)leafNum * nptn);
+    ptn_freq.assign(freq, freq + nptn);
+    ptn_invar.assign(invar, invar + nptn);
+    inputs_dirty = true;
+}
+
+void PhyloTree::setModel(int ncat_, const double *eval, const double *evec, const double *inv_evec,
+                         const double *rates, const double *props) {
+    if (num_states <= 0) throw std::runtime_error("setAlignment first");
+    if (engine && ncat_ != ncat) throw std::runtime_error("ncat cannot change after attachEngine");
+    const int n = num_states;
+    ncat = ncat_;
+    m_eval.assign(eval, eval + n);
+    m_evec.assign(evec, evec + n * n);
+    m_inv_evec.assign(inv_evec, inv_evec + n * n);
+    m_rates.assign(rates, rates + ncat);
+    m_props.assign(props, props + ncat);
+    computeTipPartialLikelihood();
+    inputs_dirty = true;
+    theta_computed = false;
+}
+
+void PhyloTree::computeTipPartialLikelihood() {
+    const int n = num_states;
+    tip_partial_lh.assign((size_t)(STATE_UNKNOWN + 1) * n, 0.0);
+    const double *inv_evec = m_inv_evec.data();
+    for (int state = 0; state < n; state++)
+        for (int i = 0; i < n; i++) tip_partial_lh[state * n + i] = inv_evec[i * n + state];
+    for (int i = 0; i < n; i++) {  // unknown character: sum over all states
+        double lh_unknown = 0.0;
+        for (int x = 0; x < n; x++) lh_unknown += inv_evec[i * n + x];
+        tip_partial_lh[STATE_UNKNOWN * n + i] = lh_unknown;
+    }
+    if (seq_type == SEQ_DNA && n == 4) {
+        for (int state = 4; state < 18; state++) {  // IUPAC ambiguity = bitmask state-3
+            const int cstate = state - n + 1;
+            for (int i = 0; i < n; i++) {
+                double lh = 0.0;
+                for (int x = 0; x < n; x++)
+                    if (cstate & (1 << x)) lh += inv_evec[i * n + x];
+                tip_partial_lh[state * n + i] = lh;
+            }
+        }
+    } else if (seq_type == SEQ_PROTEIN && n == 20) {
+        const int ambi_aa[3] = {4 + 8, 32 + 64, 512 + 1024};  // B, Z, U
+        for (int k = 0; k < 3; k++)
+            for (int i = 0; i < n; i++) {
+                double lh = 0.0;
+                for (int x = 0; x < 11; x++)
+                    if (ambi_aa[k] & (1 << x)) lh += inv_evec[i * n + x];
+                tip_partial_lh[(20 + k) * n + i] = lh;
+            }
+    }
+}
+
+void PhyloTree::check(int rc, const char *what) const {
+    if (rc != IQHIP_OK) throw std::runtime_error(std::string(what) + ": " + iqhip_last_error());
+}
+
+void PhyloTree::attachEngine(int device) {
+    if (engine) throw std::runtime_error("engine already attached");
+    if (m_eval.empty() || aln_states.empty()) throw std::runtime_error("setAlignment and setModel first");
+    check(iqhip_create(&engine, device, num_states, ncat, nptn, leafNum), "iqhip_create");
+    inputs_dirty = true;
+    pushInputs();
+    // the reference's arena: leafNum-2 vectors (LM_PER_NODE) or 3*leafNum-6 (phylotree.cpp:867-873)
+    int nvec = (lh_mem_save == LM_PER_NODE) ? (leafNum - 2) : (3 * leafNum - 6);
+    check(iqhip_reserve(engine, nvec), "iqhip_reserve");
+}
+
+void PhyloTree::pushInputs() {
+    if (!engine || !inputs_dirty) return;
+    check(iqhip_set_model(engine, m_eval.data(), m_evec.data(), m_inv_evec.data(), m_rates.data(),
+                          m_props.data(), STATE_UNKNOWN, tip_partial_lh.data()),
+          "iqhip_set_model");
+    check(iqhip_set_alignment(engine, aln_states.data(), ptn_freq.data(), ptn_invar.data()),
+          "iqhip_set_alignment");
+    inputs_dirty = false;
+}
+
+// =========================================================================================
+// dispatch (phylotreesse.cpp:60-357)
+// =========================================================================================
+void PhyloTree::setLikelihoodKernel(LikelihoodKernel lk) {
+    sse = lk;
+    if (lk != LK_EIGEN_HIP) {
+        computePartialLikelihoodPointer = nullptr;
+        computeLikelihoodBranchPointer = nullptr;
+        computeLikelihoodDervPointer = nullptr;
+        computeLikelihoodFromBufferPointer = nullptr;
+        throw std::runtime_error(
+            "setLikelihoodKernel: this build ships no CPU kernel; only LK_EIGEN_HIP is available");
+    }
+    computePartialLikelihoodPointer = &PhyloTree::computePartialLikelihoodHIP;
+    computeLikelihoodBranchPointer = &PhyloTree::computeLikelihoodBranchHIP;
+    computeLikelihoodDervPointer = &PhyloTree::computeLikelihoodDervHIP;
+    computeLikelihoodFromBufferPointer = &PhyloTree::computeLikelihoodFromBufferHIP;
+}
+
+void PhyloTree::computePartialLikelihood(PhyloNeighbor *dad_branch, PhyloNode *dad) {
+    (this->*computePartialLikelihoodPointer)(dad_branch, dad);
+}
+double PhyloTree::computeLikelihoodBranch(PhyloNeighbor *dad_branch, PhyloNode *dad) {
+    return (this->*computeLikelihoodBranchPointer)(dad_branch, dad);
+}
+void PhyloTree::computeLikelihoodDerv(PhyloNeighbor *dad_branch, PhyloNode *dad, double &df, double &ddf) {
+    (this->*computeLikelihoodDervPointer)(dad_branch, dad, df, ddf);
+}
+double PhyloTree::computeLikelihoodFromBuffer() {
+    assert(current_it && current_it_back);
+    if (computeLikelihoodFromBufferPointer) return (this->*computeLikelihoodFromBufferPointer)();
+    return (this->*computeLikelihoodBranchPointer)(current_it, current_it_back->node);
+}
+
+// =========================================================================================
+// buffers (phylotree.cpp:667-716, 834-987)
+// =========================================================================================
+void PhyloTree::initializeAllPartialLh() {
+    if (!root) throw std::runtime_error("no tree");
+    // depth-first from the root leaf, as initializeAllPartialLh(index, indexlh, node, dad)
+    struct Rec {
+        PhyloTree *t;
+        void go(PhyloNode *node, PhyloNode *dad) {
+            if (dad) {
+                PhyloNeighbor *nei = node->findNeighbor(dad);   // node -> dad
+                PhyloNeighbor *nei2 = dad->findNeighbor(node);  // dad -> node
+                if (t->lh_mem_save == LM_PER_NODE) {
+                    nei->partial_lh = 0;
+                    nei2->partial_lh = node->isLeaf() ? 0 : t->next_key++;
+                } else {
+                    nei->partial_lh = nei->node->isLeaf() ? 0 : t->next_key++;
+                    nei2->partial_lh = nei2->node->isLeaf() ? 0 : t->next_key++;
+                }
+            }
+            for (PhyloNeighbor *nb : node->neighbors)
+                if (nb->node != dad) go(nb->node, node);
+        }
+    } rec{this};
+    rec.go(root, nullptr);
+    central_partial_lh = true;
+}
+
+void PhyloTree::deleteAllPartialLh() {
+    for (PhyloNeighbor *nb : all_neighbors) {
+        if (nb->partial_lh && engine) iqhip_release(engine, nb->partial_lh);
+        nb->partial_lh = 0;
+        nb->partial_lh_computed = 0;
+    }
+    central_partial_lh = false;
+}
+
+void PhyloTree::clearAllPartialLH() {
+    if (!root) return;
+    root->neighbors[0]->node->clearAllPartialLh(false, root);
+    current_it = current_it_back = nullptr;
+}
+
+// =========================================================================================
+// plan building = phylokernel.h:70-157 without the pattern loops
+// =========================================================================================
+void PhyloTree::collectPlan(PhyloNeighbor *dad_branch, PhyloNode *dad, std::vector<PlanOp> &plan) {
+    assert(dad);
+    if (dad_branch->partial_lh_computed & 1) return;  // don't recompute (:81-82)
+    dad_branch->partial_lh_computed |= 1;
+    num_partial_lh_computations++;
+    PhyloNode *node = dad_branch->node;
+    if (node->isLeaf()) {
+        dad_branch->lh_scale_factor = 0.0;  // :93-97
+        return;
+    }
+    if (node->degree() != 3)
+        throw std::runtime_error("multifurcating node: the reference falls back to its scalar kernel "
+                                 "(phylokernel.h:73-77), which this build does not ship");
+    PhyloNeighbor *left = nullptr, *right = nullptr;
+    for (PhyloNeighbor *nb : node->neighbors)
+        if (nb->node != dad) {
+            if (!left) left = nb; else right = nb;
+        }
+    if (!left->node->isLeaf() && right->node->isLeaf()) std::swap(left, right);  // :116-121
+    if ((left->partial_lh_computed & 1) == 0) collectPlan(left, node, plan);
+    if ((right->partial_lh_computed & 1) == 0) collectPlan(right, node, plan);
+
+    if (lh_mem_save == LM_PER_NODE && !dad_branch->partial_lh) {
+        // re-orient partial_lh (:127-143): steal the vector of a child-side back neighbour
+        bool done = false;
+        for (PhyloNeighbor *nb : node->neighbors)
+            if (nb->node != dad) {
+                PhyloNeighbor *backnei = nb->node->findNeighbor(node);
+                if (backnei->partial_lh) {
+                    dad_branch->partial_lh = backnei->partial_lh;
+                    backnei->partial_lh = 0;
+                    backnei->partial_lh_computed &= ~1;
+                    done = true;
+                    break;
+                }
+            }
+        if (!done) throw std::runtime_error("partial_lh is not re-oriented");
+    }
+    if (!dad_branch->partial_lh) throw std::runtime_error("neighbor has no partial_lh buffer");
+
+    PlanOp p;
+    p.dst = dad_branch;
+    p.left = left;
+    p.right = right;
+    memset(&p.op, 0, sizeof(p.op));
+    p.op.dst_key = dad_branch->partial_lh;
+    p.op.left_leaf = left->node->isLeaf() ? left->node->id : -1;
+    p.op.right_leaf = right->node->isLeaf() ? right->node->id : -1;
+    p.op.left_key = left->node->isLeaf() ? 0 : left->partial_lh;
+    p.op.right_key = right->node->isLeaf() ? 0 : right->partial_lh;
+    p.op.left_len = left->length;
+    p.op.right_len = right->length;
+    plan.push_back(p);
+}
+
+void PhyloTree::applyScaleFactors(const std::vector<PlanOp> &plan, const std::vector<double> &sum_scale) {
+    // dad_branch->lh_scale_factor = left + right (:157) + sum_scale (:395,477), in plan order
+    for (size_t k = 0; k < plan.size(); k++)
+        plan[k].dst->lh_scale_factor =
+            plan[k].left->lh_scale_factor + plan[k].right->lh_scale_factor + sum_scale[k];
+}
+
+iqhip_branch_end PhyloTree::branchEnd(PhyloNeighbor *nei) const {
+    iqhip_branch_end e;
+    e._pad = 0;
+    if (nei->node->isLeaf()) {
+        e.key = 0;
+        e.leaf = nei->node->id;
+    } else {
+        e.key = nei->partial_lh;
+        e.leaf = -1;
+    }
+    return e;
+}
+
+void PhyloTree::computePartialLikelihoodHIP(PhyloNeighbor *dad_branch, PhyloNode *dad) {
+    if (!central_partial_lh) initializeAllPartialLh();
+    std::vector<PlanOp> plan;
+    collectPlan(dad_branch, dad, plan);
+    last_plan = plan;
+    if (plan.empty()) return;
+    std::vector<double> sum_scale(plan.size(), 0.0);
+    if (!dry_run) {
+        if (!engine) throw std::runtime_error("HIP likelihood kernel selected but no engine attached");
+        pushInputs();
+        std::vector<iqhip_node_op> ops(plan.size());
+        for (size_t k = 0; k < plan.size(); k++) ops[k] = plan[k].op;
+        check(iqhip_update_partials(engine, ops.data(), (int)ops.size(), sum_scale.data()),
+              "iqhip_update_partials");
+        num_submissions++;
+    }
+    applyScaleFactors(plan, sum_scale);
+}
+
+double PhyloTree::computeLikelihoodBranchHIP(PhyloNeighbor *dad_branch, PhyloNode *dad) {
+    PhyloNode *node = dad_branch->node;
+    PhyloNeighbor *node_branch = node->findNeighbor(dad);
+    if (!central_partial_lh) initializeAllPartialLh();
+    if (node->isLeaf()) {  // phylokernel.h:739-746
+        std::swap(dad, node);
+        std::swap(dad_branch, node_branch);
+    }
+    std::vector<PlanOp> plan;
+    if ((dad_branch->partial_lh_computed & 1) == 0) collectPlan(dad_branch, dad, plan);
+    if ((node_branch->partial_lh_computed & 1) == 0) collectPlan(node_branch, node, plan);
+    last_plan = plan;
+    std::vector<double> sum_scale(plan.size(), 0.0);
+    double lnl = 0.0;
+    if (!dry_run) {
+        if (!engine) throw std::runtime_error("HIP likelihood kernel selected but no engine attached");
+        pushInputs();
+        std::vector<iqhip_node_op> ops(plan.size());
+        for (size_t k = 0; k < plan.size(); k++) ops[k] = plan[k].op;
+        // dad_branch points at `node`'s subtree; node_branch at `dad`'s (a leaf after the swap)
+        if (allreduce_hook) {
+            check(iqhip_traverse_lnl_async(engine, ops.data(), (int)ops.size(), branchEnd(node_branch),
+                                           branchEnd(dad_branch), dad_branch->length),
+                  "iqhip_traverse_lnl_async");
+            const int nres = 2 + (int)ops.size();
+            allreduce_hook(iqhip_result_device_ptr(engine), nres, allreduce_ctx);
+            std::vector<double> res(nres);
+            check(iqhip_result_read(engine, res.data(), nres), "iqhip_result_read");
+            lnl = res[0];
+            for (size_t k = 0; k < plan.size(); k++) sum_scale[k] = res[2 + k];
+        } else {
+            check(iqhip_traverse_lnl(engine, ops.data(), (int)ops.size(), branchEnd(node_branch),
+                                     branchEnd(dad_branch), dad_branch->length, sum_scale.data(), &lnl),
+                  "iqhip_traverse_lnl");
+        }
+        num_submissions++;
+    }
+    applyScaleFactors(plan, sum_scale);
+    return node_branch->lh_scale_factor + dad_branch->lh_scale_factor + lnl;  // :751
+}
+
+void PhyloTree::computeLikelihoodDervHIP(PhyloNeighbor *dad_branch, PhyloNode *dad, double &df, double &ddf) {
+    PhyloNode *node = dad_branch->node;
+    PhyloNeighbor *node_branch = node->findNeighbor(dad);
+    if (!central_partial_lh) initializeAllPartialLh();
+    if (node->isLeaf()) {  // phylokernel.h:491-498
+        std::swap(dad, node);
+        std::swap(dad_branch, node_branch);
+    }
+    if ((dad_branch->partial_lh_computed & 1) == 0) computePartialLikelihoodHIP(dad_branch, dad);
+    if ((node_branch->partial_lh_computed & 1) == 0) computePartialLikelihoodHIP(node_branch, node);
+    df = ddf = 0.0;
+    if (dry_run) { theta_computed = true; return; }
+    if (!engine) throw std::runtime_error("HIP likelihood kernel selected but no engine attached");
+    pushInputs();
+    if (!theta_computed) {  // :535-579
+        theta_computed = true;
+        check(iqhip_compute_theta(engine, branchEnd(node_branch), branchEnd(dad_branch)), "iqhip_compute_theta");
+    }
+    if (allreduce_hook) {
+        check(iqhip_derv_async(engine, dad_branch->length), "iqhip_derv_async");
+        allreduce_hook(iqhip_result_device_ptr(engine), 2, allreduce_ctx);
+        double res[2];
+        check(iqhip_result_read(engine, res, 2), "iqhip_result_read");
+        df = res[0];
+        ddf = res[1];
+        if (isnan(df) || isinf(df)) df = ddf = 0.0;  // phylokernel.h:647-651
+    } else {
+        check(iqhip_derv(engine, dad_branch->length, &df, &ddf), "iqhip_derv");
+    }
+}
+
+double PhyloTree::computeLikelihoodFromBufferHIP() {
+    assert(current_it && current_it_back);
+    if (!theta_computed) throw std::runtime_error("computeLikelihoodFromBuffer: theta not computed");
+    double lnl = 0.0;
+    if (!dry_run) {
+        if (!engine) throw std::runtime_error("HIP likelihood kernel selected but no engine attached");
+        check(iqhip_lnl_from_theta(engine, current_it->length, &lnl), "iqhip_lnl_from_theta");
+    }
+    return current_it->lh_scale_factor + current_it_back->lh_scale_factor + lnl;  // :1028
+}
+
+// =========================================================================================
+// callers
+// =========================================================================================
+double PhyloTree::computeLikelihood(double *pattern_lh) {
+    if (!root || !root->isLeaf()) throw std::runtime_error("computeLikelihood: no rooted-at-leaf tree");
+    if (!current_it) {
+        PhyloNode *leaf = findFarthestLeaf();
+        current_it = leaf->neighbors[0];
+        current_it_back = current_it->node->findNeighbor(leaf);
+    }
+    double score = computeLikelihoodBranch(current_it, current_it_back->node);
+    if (pattern_lh) {
+        fetchPatternLh(pattern_lh);
+        if (current_it->lh_scale_factor < 0.0) {  // phylotree.cpp:1059-1069
+            std::vector<UBYTE> sc((size_t)nptn);
+            fetchScaleNum(current_it, sc.data());
+            for (int64_t i = 0; i < nptn; i++)
+                pattern_lh[i] += std::max(sc[i], UBYTE(0)) * LOG_SCALING_THRESHOLD;
+        }
+    }
+    curScore = score;
+    return score;
+}
+
+double PhyloTree::computeFuncDerv(double value, double &df, double &ddf) {
+    current_it->length = value;
+    current_it_back->length = value;
+    computeLikelihoodDerv(current_it, current_it_back->node, df, ddf);
+    df = -df;
+    ddf = -ddf;
+    return 0.0;
+}
+
+// optimization.cpp:388-465 restated (Newton-Raphson with bisection safeguard on f = -dlnL/dt)
+double PhyloTree::minimizeNewton(double x1, double xguess, double x2, double xacc, double &d2l, int maxNRStep) {
+    double df, dx, f, temp, xh, xl, rts, rts_old;
+    rts = xguess;
+    if (rts < x1) rts = x1;
+    if (rts > x2) rts = x2;
+    computeFuncDerv(rts, f, df);
+    d2l = df;
+    if (!isfinite(f) || !isfinite(df)) throw std::runtime_error("Wrong computeFuncDerv");
+    if (df >= 0.0 && fabs(f) < xacc) return rts;
+    if (f < 0.0) { xl = rts; xh = x2; } else { xh = rts; xl = x1; }
+    dx = fabs(xh - xl);
+    for (int j = 1; j <= maxNRStep; j++) {
+        rts_old = rts;
+        if ((df <= 0.0) || (((rts - xh) * df - f) * ((rts - xl) * df - f) >= 0.0)) {
+            dx = 0.5 * (xh - xl);
+            rts = xl + dx;
+            d2l = df;
+            if (xl == rts) return rts;
+        } else {
+            dx = f / df;
+            temp = rts;
+            rts -= dx;
+            d2l = df;
+            if (temp == rts) return rts;
+        }
+        if (fabs(dx) < xacc || (j == maxNRStep)) return rts_old;
+        computeFuncDerv(rts, f, df);
+        if (!isfinite(f) || !isfinite(df)) throw std::runtime_error("Wrong computeFuncDerv");
+        if (df > 0.0 && fabs(f) < xacc) { d2l = df; return rts; }
+        if (f < 0.0) xl = rts; else xh = rts;
+    }
+    throw std::runtime_error("Maximum number of iterations exceeded in minimizeNewton");
+}
+
+void PhyloTree::optimizeOneBranch(PhyloNode *node1, PhyloNode *node2, bool clearLH, int maxNRStep) {
+    current_it = node1->findNeighbor(node2);
+    current_it_back = node2->findNeighbor(node1);
+    assert(current_it && current_it_back);
+    const double current_len = current_it->length;
+    theta_computed = false;
+    double d2l;
+    double optx = minimizeNewton(min_branch_length, current_len, max_branch_length, min_branch_length, d2l, maxNRStep);
+    if (optx > max_branch_length * 0.95) {  // newton raphson diverged, reset (phylotree.cpp:2167-2176)
+        current_it->length = current_it_back->length = optx;
+        double opt_lh = computeLikelihoodFromBuffer();
+        current_it->length = current_it_back->length = current_len;
+        double orig_lh = computeLikelihoodFromBuffer();
+        if (orig_lh > opt_lh) optx = current_len;
+    }
+    current_it->length = optx;
+    current_it_back->length = optx;
+    if (clearLH && current_len != optx) {
+        node1->clearReversePartialLh(node2);
+        node2->clearReversePartialLh(node1);
+    }
+}
+
+void PhyloTree::getPreOrderBranches(std::vector<PhyloNode *> &n1, std::vector<PhyloNode *> &n2,
+                                    PhyloNode *node, PhyloNode *dad) {
+    if (dad) { n1.push_back(node); n2.push_back(dad); }
+    std::vector<PhyloNeighbor *> neivec = node->neighbors;  // mtree.cpp:2102-2113: ascending height
+    for (size_t i = 0; i < neivec.size(); i++)
+        for (size_t j = i + 1; j < neivec.size(); j++)
+            if (neivec[i]->node->height > neivec[j]->node->height) std::swap(neivec[i], neivec[j]);
+    for (PhyloNeighbor *nb : neivec)
+        if (nb->node != dad) getPreOrderBranches(n1, n2, nb->node, node);
+}
+
+double PhyloTree::optimizeAllBranches(int my_iterations, double tolerance, int maxNRStep) {
+    std::vector<PhyloNode *> nodes1, nodes2;
+    PhyloNode *farleaf = findFarthestLeaf();
+    findFarthestLeaf(farleaf);  // phylotree.cpp:2241-2250
+    getPreOrderBranches(nodes1, nodes2, farleaf, nullptr);
+    double tree_lh = computeLikelihoodBranch(nodes1[0]->findNeighbor(nodes2[0]), nodes1[0]);
+    for (int i = 0; i < my_iterations; i++) {
+        std::vector<double> lenvec;
+        for (PhyloNeighbor *nb : all_neighbors) lenvec.push_back(nb->length);
+        for (size_t j = 0; j < nodes1.size(); j++) optimizeOneBranch(nodes1[j], nodes2[j], true, maxNRStep);
+        double new_tree_lh = computeLikelihoodFromBuffer();
+        if (new_tree_lh < tree_lh) {  // rare: restore and stop (phylotree.cpp:2303-2319)
+            clearAllPartialLH();
+            for (size_t k = 0; k < all_neighbors.size(); k++) all_neighbors[k]->length = lenvec[k];
+            new_tree_lh = computeLikelihood();
+            curScore = new_tree_lh;
+            return new_tree_lh;
+        }
+        if (tree_lh <= new_tree_lh && new_tree_lh <= tree_lh + tolerance) { curScore = new_tree_lh; return new_tree_lh; }
+        tree_lh = new_tree_lh;
+    }
+    curScore = tree_lh;
+    return tree_lh;
+}
+
+// =========================================================================================
+// host views
+// =========================================================================================
+void PhyloTree::fetchScaleNum(PhyloNeighbor *nei, UBYTE *out) {
+    if (!engine) throw std::runtime_error("no engine");
+    if (!nei->partial_lh) throw std::runtime_error("neighbor has no buffer");
+    check(iqhip_fetch_scale_num(engine, nei->partial_lh, out), "iqhip_fetch_scale_num");
+}
+void PhyloTree::fetchPartialLh(PhyloNeighbor *nei, double *out) {
+    if (!engine) throw std::runtime_error("no engine");
+    if (!nei->partial_lh) throw std::runtime_error("neighbor has no buffer");
+    check(iqhip_fetch_partial(engine, nei->partial_lh, out), "iqhip_fetch_partial");
+}
+void PhyloTree::fetchPatternLh(double *out) {
+    if (!engine) throw std::runtime_error("no engine");
+    check(iqhip_fetch_pattern_lh(engine, out), "iqhip_fetch_pattern_lh");
+}
+
+}  // namespace iqhost

@@ -1,0 +1,183 @@
+// phylo_host.h -- host-side mirror of the slice of IQ-TREE's PhyloTree that sits directly on
+// top of the likelihood kernels.  It exists so that (a) the drop-in boundary can be exercised
+// exactly the way the reference's callers exercise it (setLikelihoodKernel(); clearAllPartialLH();
+// computeLikelihood(); computeLikelihoodDerv(); ...) on a box that has no reference sources,
+// and (b) the adapter logic shipped in integration/phylotree_hip.cpp (recursion, lazy flags,
+// LM_PER_NODE re-orientation, lh_scale_factor bookkeeping) is tested code.
+//
+// Names and argument meaning follow the reference (file:line = /root/reference):
+//   PhyloNeighbor fields            phylonode.h:102-127
+//   setLikelihoodKernel + 4 ptrs    phylotreesse.cpp:60-357, phylotree.h:658-659,697-698,742-743,979-980
+//   initializeAllPartialLh          phylotree.cpp:667-716,834-987   (LM_PER_NODE / LM_ALL_BRANCH)
+//   computeLikelihood               phylotree.cpp:1031-1072
+//   clear*PartialLh                 phylonode.cpp:15-65, phylotree.cpp:495-502
+//   computeTipPartialLikelihood     phylotreesse.cpp:359-529
+//   optimizeOneBranch/AllBranches   phylotree.cpp:2120-2332, optimization.cpp:388-465
+// The compute kernels themselves are NOT here: the four *HIP member functions only build a
+// plan and call libiqhip.so (include/iqhip.h).  There is no CPU kernel in this library; asking
+// for LK_EIGEN / LK_EIGEN_SSE throws.
+#pragma once
+#include <stdint.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/iqhip.h"
+
+namespace iqhost {
+
+typedef short int UBYTE;  // phylonode.h:17
+
+enum LikelihoodKernel { LK_EIGEN = 0, LK_EIGEN_SSE = 1, LK_EIGEN_HIP = 2 };  // tools.h:397-399 (+HIP)
+enum LhMemSave { LM_PER_NODE = 0, LM_ALL_BRANCH = 1 };                       // tools.cpp:907,2461
+enum SeqType { SEQ_DNA = 0, SEQ_PROTEIN = 1, SEQ_CODON = 2, SEQ_OTHER = 3 };
+
+struct PhyloNode;
+
+struct PhyloNeighbor {
+    PhyloNode *node = nullptr;  // the node this neighbor points TO
+    double length = 0.0;
+    int id = -1;                // branch id
+    int partial_lh_computed = 0;  // bit0 = likelihood vector valid (phylonode.h:104)
+    uint64_t partial_lh = 0;      // opaque device key; 0 == NULL (phylonode.h:112)
+    double lh_scale_factor = 0.0; // phylonode.h:117
+    inline void clearPartialLh() { partial_lh_computed = 0; }
+    void clearForwardPartialLh(PhyloNode *dad);  // phylonode.cpp:15-20
+};
+
+struct PhyloNode {
+    int id = -1;  // leaves: taxon id (alignment row); internal: >= leafNum
+    std::string name;
+    std::vector<PhyloNeighbor *> neighbors;
+    double height = 0.0;
+    bool isLeaf() const { return neighbors.size() <= 1; }
+    int degree() const { return (int)neighbors.size(); }
+    PhyloNeighbor *findNeighbor(const PhyloNode *n) const {
+        for (PhyloNeighbor *x : neighbors)
+            if (x->node == n) return x;
+        return nullptr;
+    }
+    void clearReversePartialLh(PhyloNode *dad);              // phylonode.cpp:42-50
+    void clearAllPartialLh(bool make_null, PhyloNode *dad);  // phylonode.cpp:52-65
+};
+
+// a recorded node update (also what the CPU-only tests inspect in dry-run mode)
+struct PlanOp {
+    PhyloNeighbor *dst, *left, *right;
+    iqhip_node_op op;
+};
+
+class PhyloTree {
+public:
+    typedef void (PhyloTree::*ComputePartialLikelihoodType)(PhyloNeighbor *, PhyloNode *);
+    typedef double (PhyloTree::*ComputeLikelihoodBranchType)(PhyloNeighbor *, PhyloNode *);
+    typedef double (PhyloTree::*ComputeLikelihoodFromBufferType)();
+    typedef void (PhyloTree::*ComputeLikelihoodDervType)(PhyloNeighbor *, PhyloNode *, double &, double &);
+
+    PhyloTree();
+    ~PhyloTree();
+    PhyloTree(const PhyloTree &) = delete;
+    PhyloTree &operator=(const PhyloTree &) = delete;
+
+    // ---- tree ----------------------------------------------------------------------------
+    // Newick with branch lengths; leaf labels are looked up in `names` (alignment order) or,
+    // when names is empty, parsed as integer taxon ids.  A bifurcating top level is unrooted.
+    void readTreeString(const std::string &newick, const std::vector<std::string> &names);
+    std::string getTreeString() const;
+    int leafNum = 0, nodeNum = 0, branchNum = 0;
+    PhyloNode *root = nullptr;  // a leaf, as in the reference (phylotree.cpp:1034)
+    std::vector<PhyloNode *> nodes;  // index == id
+    PhyloNode *findFarthestLeaf(PhyloNode *node = nullptr, PhyloNode *dad = nullptr);  // mtree.cpp:2052
+
+    // ---- data + model (the kernel's inputs, SURVEY 8a a5,a6,a13) -------------------------
+    void setAlignment(int nstates, SeqType seq_type, int64_t nptn, const uint8_t *states /*[leaf][ptn]*/,
+                      const double *ptn_freq, const double *ptn_invar);
+    void setModel(int ncat, const double *eval, const double *evec, const double *inv_evec,
+                  const double *rates, const double *props);
+    int num_states = 0, ncat = 0, STATE_UNKNOWN = 0;
+    SeqType seq_type = SEQ_DNA;
+    int64_t nptn = 0;
+    std::vector<double> tip_partial_lh;
+    void computeTipPartialLikelihood();  // phylotreesse.cpp:459-527
+
+    // ---- kernel dispatch -----------------------------------------------------------------
+    void setLikelihoodKernel(LikelihoodKernel lk);  // phylotreesse.cpp:60
+    LikelihoodKernel sse = LK_EIGEN_HIP;
+    LhMemSave lh_mem_save = LM_PER_NODE;
+    // device: >= 0 creates an engine on that GPU; dry_run records plans without any device
+    void attachEngine(int device);
+    void setDryRun(bool on) { dry_run = on; }
+    iqhip_engine *engine = nullptr;
+    // Pattern-sharded runs (one process per GPU): when set, every host-visible result vector
+    // {lnL | df,ddf | sum_scale per op} is left on the device, handed to this hook (which
+    // all-reduces it in place over RCCL on the engine's stream) and only then read back.
+    typedef void (*AllReduceHook)(void *device_ptr, int ndoubles, void *ctx);
+    void setAllReduceHook(AllReduceHook fn, void *ctx) { allreduce_hook = fn; allreduce_ctx = ctx; }
+
+    void computePartialLikelihood(PhyloNeighbor *dad_branch, PhyloNode *dad);       // :335
+    double computeLikelihoodBranch(PhyloNeighbor *dad_branch, PhyloNode *dad);      // :339
+    void computeLikelihoodDerv(PhyloNeighbor *dad_branch, PhyloNode *dad, double &df, double &ddf);  // :344
+    double computeLikelihoodFromBuffer();                                           // :349
+
+    // ---- buffers / flags -----------------------------------------------------------------
+    void initializeAllPartialLh();  // phylotree.cpp:667
+    void deleteAllPartialLh();      // phylotree.cpp:718
+    void clearAllPartialLH();       // phylotree.cpp:495
+    bool central_partial_lh = false;
+    bool theta_computed = false;
+    PhyloNeighbor *current_it = nullptr, *current_it_back = nullptr;
+
+    // ---- callers (hot loops 1 and 2 of SURVEY section 3) -----------------------------------
+    double computeLikelihood(double *pattern_lh = nullptr);  // phylotree.cpp:1031
+    double curScore = 0.0;
+    double min_branch_length = 1e-6, max_branch_length = 100.0;  // tools.cpp defaults
+    void optimizeOneBranch(PhyloNode *node1, PhyloNode *node2, bool clearLH = true, int maxNRStep = 100);
+    double optimizeAllBranches(int my_iterations = 100, double tolerance = 0.001, int maxNRStep = 100);
+
+    // ---- host views ----------------------------------------------------------------------
+    void fetchScaleNum(PhyloNeighbor *nei, UBYTE *out);
+    void fetchPartialLh(PhyloNeighbor *nei, double *out);
+    void fetchPatternLh(double *out);
+
+    std::vector<PlanOp> last_plan;  // the most recent submission (tests / tracing)
+    long num_partial_lh_computations = 0;  // phylokernel.h:85 (counts leaf visits too)
+    long num_submissions = 0;
+
+private:
+    ComputePartialLikelihoodType computePartialLikelihoodPointer = nullptr;
+    ComputeLikelihoodBranchType computeLikelihoodBranchPointer = nullptr;
+    ComputeLikelihoodFromBufferType computeLikelihoodFromBufferPointer = nullptr;
+    ComputeLikelihoodDervType computeLikelihoodDervPointer = nullptr;
+
+    // the four kernels registered for LK_EIGEN_HIP
+    void computePartialLikelihoodHIP(PhyloNeighbor *dad_branch, PhyloNode *dad);
+    double computeLikelihoodBranchHIP(PhyloNeighbor *dad_branch, PhyloNode *dad);
+    void computeLikelihoodDervHIP(PhyloNeighbor *dad_branch, PhyloNode *dad, double &df, double &ddf);
+    double computeLikelihoodFromBufferHIP();
+
+    // plan building: the reference's recursion (phylokernel.h:70-157) with the pattern loop
+    // replaced by "append one op"
+    void collectPlan(PhyloNeighbor *dad_branch, PhyloNode *dad, std::vector<PlanOp> &plan);
+    void applyScaleFactors(const std::vector<PlanOp> &plan, const std::vector<double> &sum_scale);
+    iqhip_branch_end branchEnd(PhyloNeighbor *nei) const;
+    void check(int rc, const char *what) const;
+    void pushInputs();
+
+    double computeFuncDerv(double value, double &df, double &ddf);
+    double minimizeNewton(double x1, double xguess, double x2, double xacc, double &d2l, int maxNRStep);
+    void getPreOrderBranches(std::vector<PhyloNode *> &n1, std::vector<PhyloNode *> &n2, PhyloNode *node,
+                             PhyloNode *dad);
+
+    AllReduceHook allreduce_hook = nullptr;
+    void *allreduce_ctx = nullptr;
+    bool dry_run = false;
+    bool inputs_dirty = true;
+    uint64_t next_key = 1;
+    std::vector<uint8_t> aln_states;
+    std::vector<double> ptn_freq, ptn_invar, m_eval, m_evec, m_inv_evec, m_rates, m_props;
+    std::vector<PhyloNeighbor *> all_neighbors;
+    void freeTree();
+};
+
+}  // namespace iqhost

@@ -1,0 +1,248 @@
+"""Synthetic inputs for tests and bench.py: reversible substitution models in the eigen form the
+kernels consume, discrete-Gamma rates, random trees and sequence simulation.
+
+These are INPUT GENERATORS, not part of the accelerated path.  The decomposition follows the
+recipe the reference uses for reversible models (eigendecomposition.cpp:167-296,306-394:
+normalise Q to one expected substitution per unit time, symmetrise with sqrt(pi), U = V/sqrt(pi),
+U^-1 = V^T*sqrt(pi)) so that the eigen-space vectors look like the reference's (entries of
+either sign); parity tests feed the SAME arrays to the oracle and to the HIP engine, so any
+valid eigen-system would do.
+"""
+import numpy as np
+
+try:
+    from scipy.special import gammainc
+    from scipy.stats import gamma as _gamma_dist
+except Exception:  # pragma: no cover
+    gammainc = None
+    _gamma_dist = None
+
+
+class Model:
+    """eval[n], evec[n*n] (U[x][i] at x*n+i), inv_evec[n*n] (U^-1[i][x] at i*n+x), rates, props."""
+
+    def __init__(self, Q, freqs, eval_, evec, inv_evec, rates, props, pinvar=0.0, name=""):
+        self.Q = Q
+        self.freqs = np.asarray(freqs, dtype=np.float64)
+        self.eval = np.ascontiguousarray(eval_, dtype=np.float64)
+        self.evec = np.ascontiguousarray(evec, dtype=np.float64).reshape(-1)
+        self.inv_evec = np.ascontiguousarray(inv_evec, dtype=np.float64).reshape(-1)
+        self.rates = np.ascontiguousarray(rates, dtype=np.float64)
+        self.props = np.ascontiguousarray(props, dtype=np.float64)
+        self.pinvar = float(pinvar)
+        self.name = name
+        self.nstates = len(self.eval)
+        self.ncat = len(self.rates)
+
+
+def discrete_gamma_rates(alpha, ncat, pinvar=0.0):
+    """Mean-of-category discrete Gamma (Yang 1994), mean 1, divided by (1-pinvar) as
+    model/rategamma.cpp:86-130 does."""
+    if ncat == 1:
+        return np.array([1.0 / (1.0 - pinvar)])
+    if gammainc is None:
+        raise RuntimeError("scipy is required for discrete_gamma_rates")
+    cuts = _gamma_dist.ppf(np.arange(1, ncat) / ncat, a=alpha, scale=1.0 / alpha)
+    upper = np.concatenate([gammainc(alpha + 1.0, cuts * alpha), [1.0]])
+    lower = np.concatenate([[0.0], upper[:-1]])
+    rates = (upper - lower) * ncat
+    rates = rates / rates.mean()
+    return rates / (1.0 - pinvar)
+
+
+def reversible_model(exch, freqs, alpha=None, ncat=1, pinvar=0.0, name=""):
+    """exch: symmetric n x n exchangeabilities (diagonal ignored); freqs: stationary distribution."""
+    freqs = np.asarray(freqs, dtype=np.float64)
+    freqs = freqs / freqs.sum()
+    n = len(freqs)
+    R = np.array(exch, dtype=np.float64)
+    R = (R + R.T) / 2.0
+    np.fill_diagonal(R, 0.0)
+    Q = R * freqs[None, :]
+    np.fill_diagonal(Q, -Q.sum(axis=1))
+    Q = Q / -(freqs * np.diag(Q)).sum()
+    sq = np.sqrt(freqs)
+    S = Q * sq[:, None] / sq[None, :]
+    S = (S + S.T) / 2.0
+    w, V = np.linalg.eigh(S)
+    evec = V / sq[:, None]          # U[x][i]
+    inv_evec = V.T * sq[None, :]    # U^-1[i][x]
+    if alpha is None:
+        rates = np.array([1.0 / (1.0 - pinvar)])
+        ncat = 1
+    else:
+        rates = discrete_gamma_rates(alpha, ncat, pinvar)
+    props = np.full(ncat, (1.0 - pinvar) / ncat)
+    return Model(Q, freqs, w, evec, inv_evec, rates, props, pinvar, name)
+
+
+def gtr_model(rates6=(1.5, 2.4, 1.8, 1.9, 2.8, 1.0), freqs=(0.25, 0.26, 0.25, 0.24), alpha=0.9, ncat=4,
+              pinvar=0.0):
+    """GTR{AC,AG,AT,CG,CT,GT}+F{..}+G4{alpha}: the survey's DNA benchmark model."""
+    a, b, c, d, e, f = rates6
+    R = np.array([[0, a, b, c], [a, 0, d, e], [b, d, 0, f], [c, e, f, 0]], dtype=np.float64)
+    return reversible_model(R, freqs, alpha, ncat, pinvar, name="GTR+G%d" % ncat)
+
+
+def random_reversible_model(n, seed, alpha=0.9, ncat=4, pinvar=0.0, min_freq=None):
+    """A random general time-reversible model on n states (stand-in for LG / GY: the reference's
+    empirical matrices are constants of its source and are not copied)."""
+    rng = np.random.default_rng(seed)
+    R = rng.gamma(shape=1.0, scale=1.0, size=(n, n)) + 0.05
+    freqs = rng.dirichlet(np.full(n, 5.0))
+    if min_freq:
+        freqs = np.maximum(freqs, min_freq)
+    return reversible_model(R, freqs, alpha, ncat, pinvar, name="GTR%d+G%d" % (n, ncat))
+
+
+# -------------------------------------------------------------------------------------------
+# trees
+# -------------------------------------------------------------------------------------------
+def random_tree_newick(ntaxa, seed, lo=0.02, hi=0.2, caterpillar=False):
+    """Random unrooted binary tree by random pairwise joining, branch lengths U(lo,hi).
+    Leaves are labelled with their taxon id."""
+    rng = np.random.default_rng(seed)
+    items = [str(i) for i in range(ntaxa)]
+    if caterpillar:
+        order = list(rng.permutation(ntaxa))
+        cur = "%d" % order[0]
+        first = True
+        for t in order[1:-2]:
+            l1, l2 = rng.uniform(lo, hi, 2)
+            cur = "(%s:%.6f,%d:%.6f)" % (cur, l1, t, l2)
+        l = rng.uniform(lo, hi, 3)
+        return "(%s:%.6f,%d:%.6f,%d:%.6f);" % (cur, l[0], order[-2], l[1], order[-1], l[2])
+    while len(items) > 3:
+        i, j = sorted(rng.choice(len(items), 2, replace=False))
+        l1, l2 = rng.uniform(lo, hi, 2)
+        new = "(%s:%.6f,%s:%.6f)" % (items[i], l1, items[j], l2)
+        items = [x for k, x in enumerate(items) if k not in (i, j)] + [new]
+    l = rng.uniform(lo, hi, 3)
+    return "(%s:%.6f,%s:%.6f,%s:%.6f);" % (items[0], l[0], items[1], l[1], items[2], l[2])
+
+
+def parse_newick(s):
+    """-> nested (label, length, children) tuples; minimal parser for the generator's output."""
+    pos = [0]
+
+    def node():
+        kids = []
+        if s[pos[0]] == "(":
+            pos[0] += 1
+            while True:
+                kids.append(node())
+                if s[pos[0]] == ",":
+                    pos[0] += 1
+                    continue
+                if s[pos[0]] == ")":
+                    pos[0] += 1
+                    break
+        b = pos[0]
+        while s[pos[0]] not in ":,();":
+            pos[0] += 1
+        label = s[b:pos[0]]
+        length = 0.0
+        if s[pos[0]] == ":":
+            pos[0] += 1
+            b = pos[0]
+            while s[pos[0]] not in ",();":
+                pos[0] += 1
+            length = float(s[b:pos[0]])
+        return (label, length, kids)
+
+    return node()
+
+
+# -------------------------------------------------------------------------------------------
+# simulation
+# -------------------------------------------------------------------------------------------
+def transition_matrices(model, t):
+    """P[c] = U diag(exp(eval*rate_c*t)) U^-1, rows renormalised."""
+    n = model.nstates
+    U = model.evec.reshape(n, n)
+    Ui = model.inv_evec.reshape(n, n)
+    out = []
+    for r in model.rates:
+        P = (U * np.exp(model.eval * r * t)[None, :]) @ Ui
+        P = np.clip(P, 0.0, None)
+        out.append(P / P.sum(axis=1, keepdims=True))
+    return out
+
+
+def simulate_alignment(newick, model, nsites, seed, missing_frac=0.0, state_unknown=None):
+    """Evolve nsites sites down the tree under `model` (category per site drawn from props).
+    Returns states[ntaxa][nsites] uint8."""
+    rng = np.random.default_rng(seed)
+    tree = parse_newick(newick)
+    n = model.nstates
+    cat = rng.integers(0, model.ncat, nsites)
+    root_states = rng.choice(n, size=nsites, p=model.freqs)
+    leaves = {}
+
+    def evolve(parent_states, t):
+        Ps = transition_matrices(model, t)
+        child = np.empty(nsites, dtype=np.int64)
+        u = rng.random(nsites)
+        for c in range(model.ncat):
+            idx = np.nonzero(cat == c)[0]
+            if idx.size == 0:
+                continue
+            cdf = np.cumsum(Ps[c], axis=1)
+            rows = cdf[parent_states[idx]]
+            child[idx] = np.minimum((u[idx, None] > rows).sum(axis=1), n - 1)
+        return child
+
+    def walk(nd, states):
+        label, _, kids = nd
+        if not kids:
+            leaves[int(label)] = states
+            return
+        for k in kids:
+            walk(k, evolve(states, k[1]))
+
+    walk(tree, root_states)
+    ntaxa = len(leaves)
+    out = np.empty((ntaxa, nsites), dtype=np.uint8)
+    for i in range(ntaxa):
+        out[i] = leaves[i]
+    if missing_frac > 0.0:
+        mask = rng.random(out.shape) < missing_frac
+        out[mask] = state_unknown if state_unknown is not None else n
+    return out
+
+
+def compress_patterns(states):
+    """site columns -> unique patterns (first-occurrence order) + frequencies
+    (alignment.cpp:674 addPattern keeps first-occurrence order)."""
+    cols = np.ascontiguousarray(states.T)
+    view = cols.view([("", cols.dtype)] * cols.shape[1]).reshape(-1)
+    _, first, counts = np.unique(view, return_index=True, return_counts=True)
+    order = np.argsort(first)
+    pat = cols[first[order]]
+    return np.ascontiguousarray(pat.T), counts[order].astype(np.float64)
+
+
+def ptn_invar_for(states, model):
+    """phylotreesse.cpp:543-569: p_invar*pi[const state] for constant patterns, else 0."""
+    nptn = states.shape[1]
+    out = np.zeros(nptn)
+    if model.pinvar == 0.0:
+        return out
+    n = model.nstates
+    first = states[0]
+    const = np.all(states == first[None, :], axis=0) & (first < n)
+    out[const] = model.pinvar * model.freqs[first[const]]
+    return out
+
+
+def make_workload(ntaxa, npatterns, model, seed, missing_frac=0.0, state_unknown=None):
+    """Tree + exactly `npatterns` distinct patterns with frequencies (the named BASELINE shapes)."""
+    nwk = random_tree_newick(ntaxa, seed)
+    nsites = int(npatterns * 1.02) + 64
+    for _ in range(8):
+        st = simulate_alignment(nwk, model, nsites, seed + 1, missing_frac, state_unknown)
+        pat, freq = compress_patterns(st)
+        if pat.shape[1] >= npatterns:
+            return nwk, np.ascontiguousarray(pat[:, :npatterns]), freq[:npatterns].copy()
+        nsites = int(nsites * 1.5)
+    raise RuntimeError("could not reach the requested number of distinct patterns")

@@ -1,0 +1,351 @@
+/*
+ * lh_oracle.c -- CPU restatement of IQ-TREE 1.4.3's eigen-space Felsenstein-pruning
+ * likelihood kernels (the AVX <Vec4d,4,nstates> behaviour).
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it; the product path (libiqhip.so) never does.
+ *
+ * PARITY STATUS: "parity unpinned" by execution of the reference's likelihood functions.
+ * The reference kernels are PhyloTree members whose translation units need the
+ * cmake-generated iqtree_config.h (tools.h:24), so they cannot be built in this image
+ * without the reference's own build system.  What IS pinned:
+ *   - the elementary arithmetic the kernels are made of (Vec4d mul_add / horizontal_add /
+ *     exp / log) against the reference's own vectorclass headers, compiled in place by
+ *     oracle/Makefile into oracle/_ref/vcl_probe (fixtures: tests/golden/vcl_probe.json);
+ *   - the mathematics against an independent probability-space pruning implementation
+ *     (tests/textbook.py: expm(Qt) + classical Felsenstein recursion).
+ * Every function below cites the reference lines it restates (paths relative to the
+ * reference root).
+ *
+ * Data layout = the reference's host layout (phylonode.h:102-127):
+ *   partial_lh[ptn*block + c*n + i]   (i = eigen index), block = n*ncat
+ *   scale_num[ptn]                    (short, "UBYTE" phylonode.h:17)
+ *   evec[x*n+i] = U[x][i],  inv_evec[i*n+x] = U^-1[i][x]
+ *
+ * Summation order follows the AVX kernels (no -mfma => mul_add is an unfused a*b+c,
+ * vectorclass/vectorf256.h:1870-1877): an n-term dot product is 4 lane accumulators
+ * (lane k takes terms k, k+4, ...) combined as (l0+l1)+(l2+l3) (phylokernel.h:31-43).
+ * Build with -ffp-contract=off so gcc does not fuse.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+
+#define SCALING_THRESHOLD_INVER 0x1p256                  /* 2^256   phylotree.h:51 */
+#define SCALING_THRESHOLD 0x1p-256                       /* 2^-256  phylotree.h:52 */
+#define LOG_SCALING_THRESHOLD log(SCALING_THRESHOLD)     /* phylotree.h:53 */
+
+enum { ORACLE_SEQ_DNA = 0, ORACLE_SEQ_PROTEIN = 1, ORACLE_SEQ_CODON = 2, ORACLE_SEQ_OTHER = 3 };
+
+/* (l0+l1)+(l2+l3) with lane k = sum_i a[4i+k]*b[4i+k], unfused; phylokernel.h:427-441 */
+static inline double dot4(const double *a, const double *b, int n) {
+    double l0 = a[0] * b[0], l1 = a[1] * b[1], l2 = a[2] * b[2], l3 = a[3] * b[3];
+    for (int i = 4; i < n; i += 4) {
+        l0 = a[i] * b[i] + l0;
+        l1 = a[i + 1] * b[i + 1] + l1;
+        l2 = a[i + 2] * b[i + 2] + l2;
+        l3 = a[i + 3] * b[i + 3] + l3;
+    }
+    return (l0 + l1) + (l2 + l3);
+}
+
+/* exported for tests/test_vcl_probe.py */
+double oracle_dot4(const double *a, const double *b, int n) { return dot4(a, b, n); }
+double oracle_exp(double x) { return exp(x); }
+double oracle_log(double x) { return log(x); }
+double oracle_scaling_threshold(void) { return SCALING_THRESHOLD; }
+double oracle_log_scaling_threshold(void) { return LOG_SCALING_THRESHOLD; }
+
+/* phylotreesse.cpp:459-527 -- tip vectors = columns of U^-1; unknown = row sums;
+ * DNA states 4..17 = bitmask (state-3); protein 20..22 = B,Z,U. Table has
+ * (state_unknown+1) rows of n doubles; rows the reference leaves untouched are zeroed. */
+void oracle_tip_partial_lh(int n, int seq_type, int state_unknown,
+                           const double *inv_evec, double *tip) {
+    memset(tip, 0, sizeof(double) * (size_t)(state_unknown + 1) * n);
+    for (int state = 0; state < n; state++)
+        for (int i = 0; i < n; i++) tip[state * n + i] = inv_evec[i * n + state];
+    for (int i = 0; i < n; i++) {
+        double s = 0.0;
+        for (int x = 0; x < n; x++) s += inv_evec[i * n + x];
+        tip[state_unknown * n + i] = s;
+    }
+    if (seq_type == ORACLE_SEQ_DNA && n == 4) {
+        for (int state = 4; state < 18 && state < state_unknown; state++) {
+            int cstate = state - n + 1;
+            for (int i = 0; i < n; i++) {
+                double s = 0.0;
+                for (int x = 0; x < n; x++)
+                    if (cstate & (1 << x)) s += inv_evec[i * n + x];
+                tip[state * n + i] = s;
+            }
+        }
+    } else if (seq_type == ORACLE_SEQ_PROTEIN && n == 20) {
+        static const int ambi_aa[3] = {4 + 8, 32 + 64, 512 + 1024};
+        for (int k = 0; k < 3 && 20 + k < state_unknown; k++)
+            for (int i = 0; i < n; i++) {
+                double s = 0.0;
+                for (int x = 0; x < 11; x++)
+                    if (ambi_aa[k] & (1 << x)) s += inv_evec[i * n + x];
+                tip[(20 + k) * n + i] = s;
+            }
+    }
+}
+
+/* K1, phylokernel.h:159-181: E[c][x][i] = U[x][i]*exp(eval[i]*(rate_c*len)). */
+void oracle_echild(int n, int ncat, const double *eval, const double *evec,
+                   const double *rates, double len, double *E) {
+    for (int c = 0; c < ncat; c++) {
+        double l = rates[c] * len;
+        for (int x = 0; x < n; x++)
+            for (int i = 0; i < n; i++)
+                E[(size_t)c * n * n + x * n + i] = evec[x * n + i] * exp(eval[i] * l);
+    }
+}
+
+/* K2, phylokernel.h:187-232,293-317: table[state][c*n+x] = dot4(E[c][x][:], tip[state][:]);
+ * the STATE_UNKNOWN row is exactly 1.0. */
+void oracle_tip_table(int n, int ncat, int state_unknown, const double *E,
+                      const double *tip, double *table) {
+    size_t block = (size_t)n * ncat;
+    for (int state = 0; state < state_unknown; state++)
+        for (int c = 0; c < ncat; c++)
+            for (int x = 0; x < n; x++)
+                table[state * block + c * n + x] =
+                    dot4(&E[(size_t)c * n * n + x * n], &tip[state * n], n);
+    for (size_t x = 0; x < block; x++) table[state_unknown * block + x] = 1.0;
+}
+
+/*
+ * a7 / K3-K5, phylokernel.h:183-479.  One internal-node update in the reference's layout.
+ * left_states/right_states != NULL marks a leaf child (one state byte per pattern,
+ * alignment.cpp:470-472 encoding); otherwise left_plh/left_scale are the child's vectors.
+ * As in the reference the caller passes the leaf (if exactly one) as `left`
+ * (phylokernel.h:116-121).  Returns sum_scale (the amount added to lh_scale_factor).
+ */
+double oracle_partial_update(int n, int ncat, size_t nptn,
+                             const double *eval, const double *evec, const double *inv_evec,
+                             const double *rates, const double *tip, int state_unknown,
+                             const uint8_t *left_states, const double *left_plh,
+                             const short *left_scale, double left_len,
+                             const uint8_t *right_states, const double *right_plh,
+                             const short *right_scale, double right_len,
+                             const double *ptn_freq, const double *ptn_invar,
+                             double *out_plh, short *out_scale) {
+    size_t block = (size_t)n * ncat;
+    double *EL = (double *)malloc(sizeof(double) * block * n);
+    double *ER = (double *)malloc(sizeof(double) * block * n);
+    double *tmp = (double *)malloc(sizeof(double) * n);
+    double *tabL = NULL, *tabR = NULL;
+    double sum_scale = 0.0;
+    oracle_echild(n, ncat, eval, evec, rates, left_len, EL);
+    oracle_echild(n, ncat, eval, evec, rates, right_len, ER);
+    if (left_states) {
+        tabL = (double *)malloc(sizeof(double) * (state_unknown + 1) * block);
+        oracle_tip_table(n, ncat, state_unknown, EL, tip, tabL);
+    }
+    if (right_states) {
+        tabR = (double *)malloc(sizeof(double) * (state_unknown + 1) * block);
+        oracle_tip_table(n, ncat, state_unknown, ER, tip, tabR);
+    }
+    for (size_t ptn = 0; ptn < nptn; ptn++) {
+        double *out = out_plh + ptn * block;
+        const double *tl = left_states ? tabL + (size_t)left_states[ptn] * block : NULL;
+        const double *tr = right_states ? tabR + (size_t)right_states[ptn] * block : NULL;
+        const double *pl = left_states ? NULL : left_plh + ptn * block;
+        const double *pr = right_states ? NULL : right_plh + ptn * block;
+        double lh_max = 0.0;
+        /* scale_num init: TIP-TIP 0 (:247); TIP-INT copy of right (:290); INT-INT sum (:418) */
+        short sc = 0;
+        if (!left_states) sc = (short)(sc + left_scale[ptn]);
+        if (!right_states) sc = (short)(sc + right_scale[ptn]);
+        for (int c = 0; c < ncat; c++) {
+            for (int x = 0; x < n; x++) {
+                double a = tl ? tl[c * n + x] : dot4(&EL[(size_t)c * n * n + x * n], &pl[c * n], n);
+                double b = tr ? tr[c * n + x] : dot4(&ER[(size_t)c * n * n + x * n], &pr[c * n], n);
+                tmp[x] = a * b;
+            }
+            for (int i = 0; i < n; i++) {
+                double r = dot4(tmp, &inv_evec[i * n], n);
+                out[c * n + i] = r;
+                double ar = fabs(r);
+                if (ar > lh_max) lh_max = ar;
+            }
+        }
+        /* the TIP-TIP case has no scaling check at all (phylokernel.h:246-281) */
+        if (!(left_states && right_states) &&
+            lh_max < SCALING_THRESHOLD && ptn_invar[ptn] == 0.0) {
+            for (size_t i = 0; i < block; i++) out[i] *= SCALING_THRESHOLD_INVER;
+            sum_scale += LOG_SCALING_THRESHOLD * ptn_freq[ptn];
+            sc = (short)(sc + 1);
+        }
+        out_scale[ptn] = sc;
+    }
+    free(EL); free(ER); free(tmp); free(tabL); free(tabR);
+    return sum_scale;
+}
+
+/* val[c*n+i] = exp(eval[i]*rate_c*len)*prop_c  (phylokernel.h:767-775) */
+static void branch_val(int n, int ncat, const double *eval, const double *rates,
+                       const double *props, double len, double *val) {
+    for (int c = 0; c < ncat; c++) {
+        double l = rates[c] * len;
+        for (int i = 0; i < n; i++) val[c * n + i] = exp(eval[i] * l) * props[c];
+    }
+}
+
+/* lane-strided running sum over patterns then (l0+l1)+(l2+l3):
+ * phylokernel.h:836,954 + vectorclass/vectorf256.h:1652-1657 */
+typedef struct { double l[4]; } lane4;
+static inline void lane4_acc(lane4 *s, size_t ptn, double v, double f) {
+    s->l[ptn & 3] = v * f + s->l[ptn & 3];
+}
+static inline double lane4_sum(const lane4 *s) { return (s->l[0] + s->l[1]) + (s->l[2] + s->l[3]); }
+
+/*
+ * a8 / K6, phylokernel.h:733-1020 (no ascertainment-bias patterns).
+ * dad_states != NULL: `dad` is a leaf (tip-internal form :779-866) and node_plh is the
+ * internal side; otherwise internal-internal (:912-966) on dad_plh/node_plh.
+ * Writes pattern_lh[ptn] = log|lh_ptn| and returns sum_ptn f*log|lh_ptn| -- the caller
+ * adds the two lh_scale_factors (:751).  Includes the NaN/Inf repair of :848-866.
+ */
+double oracle_branch_lnl(int n, int ncat, size_t nptn, const double *eval,
+                         const double *rates, const double *props, double len,
+                         const double *tip, const uint8_t *dad_states, const double *dad_plh,
+                         const double *node_plh, const double *ptn_freq,
+                         const double *ptn_invar, double *pattern_lh) {
+    size_t block = (size_t)n * ncat;
+    double *val = (double *)malloc(sizeof(double) * block);
+    branch_val(n, ncat, eval, rates, props, len, val);
+    lane4 fin = {{0, 0, 0, 0}};
+    for (size_t ptn = 0; ptn < nptn; ptn++) {
+        const double *b = node_plh + ptn * block;
+        double l[4];
+        if (dad_states) {
+            const double *t = tip + (size_t)dad_states[ptn] * n;
+            for (int k = 0; k < 4; k++) l[k] = (val[k] * t[k % n]) * b[k];
+            for (size_t i = 4; i < block; i += 4)
+                for (int k = 0; k < 4; k++)
+                    l[k] = (val[i + k] * t[(i + k) % n]) * b[i + k] + l[k];
+        } else {
+            const double *a = dad_plh + ptn * block;
+            for (int k = 0; k < 4; k++) l[k] = 0.0;
+            for (size_t i = 0; i < block; i += 4)
+                for (int k = 0; k < 4; k++)
+                    l[k] = (val[i + k] * b[i + k]) * a[i + k] + l[k];
+        }
+        double lh = ((l[0] + l[1]) + (l[2] + l[3])) + ptn_invar[ptn];
+        lh = log(fabs(lh));
+        pattern_lh[ptn] = lh;
+        lane4_acc(&fin, ptn, lh, ptn_freq[ptn]);
+    }
+    double tree_lh = lane4_sum(&fin);
+    if (isnan(tree_lh) || isinf(tree_lh)) {
+        tree_lh = 0.0;
+        for (size_t ptn = 0; ptn < nptn; ptn++) {
+            if (isnan(pattern_lh[ptn]) || isinf(pattern_lh[ptn]))
+                pattern_lh[ptn] = LOG_SCALING_THRESHOLD * 4;
+            tree_lh += pattern_lh[ptn] * ptn_freq[ptn];
+        }
+    }
+    free(val);
+    return tree_lh;
+}
+
+/* K7, phylokernel.h:535-573: theta = tip(state) .* dad_plh (leaf form) or node_plh .* dad_plh */
+void oracle_theta(int n, int ncat, size_t nptn, const double *tip,
+                  const uint8_t *dad_states, const double *dad_plh, const double *node_plh,
+                  double *theta) {
+    size_t block = (size_t)n * ncat;
+    for (size_t ptn = 0; ptn < nptn; ptn++) {
+        const double *b = node_plh + ptn * block;
+        double *th = theta + ptn * block;
+        if (dad_states) {
+            const double *t = tip + (size_t)dad_states[ptn] * n;
+            for (size_t i = 0; i < block; i++) th[i] = t[i % n] * b[i];
+        } else {
+            const double *a = dad_plh + ptn * block;
+            for (size_t i = 0; i < block; i++) th[i] = a[i] * b[i];
+        }
+    }
+}
+
+/* a9 / K8, phylokernel.h:516-532,583-651: df, ddf from theta at branch length len. */
+void oracle_derv(int n, int ncat, size_t nptn, const double *eval, const double *rates,
+                 const double *props, double len, const double *theta,
+                 const double *ptn_freq, const double *ptn_invar, double *df, double *ddf) {
+    size_t block = (size_t)n * ncat;
+    double *v0 = (double *)malloc(sizeof(double) * block * 3);
+    double *v1 = v0 + block, *v2 = v1 + block;
+    for (int c = 0; c < ncat; c++)
+        for (int i = 0; i < n; i++) {
+            double cof = eval[i] * rates[c];
+            double val = exp(cof * len) * props[c];
+            v0[c * n + i] = val;
+            v1[c * n + i] = cof * val;
+            v2[c * n + i] = cof * v1[c * n + i];
+        }
+    lane4 sdf = {{0, 0, 0, 0}}, sddf = {{0, 0, 0, 0}};
+    for (size_t ptn = 0; ptn < nptn; ptn++) {
+        const double *th = theta + ptn * block;
+        double p[4], d1[4], d2[4];
+        for (int k = 0; k < 4; k++) {
+            p[k] = v0[k] * th[k]; d1[k] = v1[k] * th[k]; d2[k] = v2[k] * th[k];
+        }
+        for (size_t i = 4; i < block; i += 4)
+            for (int k = 0; k < 4; k++) {
+                p[k] = th[i + k] * v0[i + k] + p[k];
+                d1[k] = th[i + k] * v1[i + k] + d1[k];
+                d2[k] = th[i + k] * v2[i + k] + d2[k];
+            }
+        double lh = ((p[0] + p[1]) + (p[2] + p[3])) + ptn_invar[ptn];
+        double inv = 1.0 / fabs(lh);
+        double dfp = ((d1[0] + d1[1]) + (d1[2] + d1[3])) * inv;
+        double ddfp = ((d2[0] + d2[1]) + (d2[2] + d2[3])) * inv;
+        ddfp = ddfp - dfp * dfp;
+        lane4_acc(&sdf, ptn, dfp, ptn_freq[ptn]);
+        lane4_acc(&sddf, ptn, ddfp, ptn_freq[ptn]);
+    }
+    *df = lane4_sum(&sdf);
+    *ddf = lane4_sum(&sddf);
+    if (isnan(*df) || isinf(*df)) { *df = 0.0; *ddf = 0.0; }
+    free(v0);
+}
+
+/* a10 / K9, phylokernel.h:1022-1122: lnL from theta (caller adds both lh_scale_factors). */
+double oracle_lnl_from_theta(int n, int ncat, size_t nptn, const double *eval,
+                             const double *rates, const double *props, double len,
+                             const double *theta, const double *ptn_freq,
+                             const double *ptn_invar, double *pattern_lh) {
+    size_t block = (size_t)n * ncat;
+    double *val = (double *)malloc(sizeof(double) * block);
+    for (int c = 0; c < ncat; c++)
+        for (int i = 0; i < n; i++) {
+            double cof = eval[i] * rates[c];
+            val[c * n + i] = exp(cof * len) * props[c];
+        }
+    lane4 fin = {{0, 0, 0, 0}};
+    for (size_t ptn = 0; ptn < nptn; ptn++) {
+        const double *th = theta + ptn * block;
+        double p[4];
+        for (int k = 0; k < 4; k++) p[k] = val[k] * th[k];
+        for (size_t i = 4; i < block; i += 4)
+            for (int k = 0; k < 4; k++) p[k] = th[i + k] * val[i + k] + p[k];
+        double lh = ((p[0] + p[1]) + (p[2] + p[3])) + ptn_invar[ptn];
+        lh = log(fabs(lh));
+        pattern_lh[ptn] = lh;
+        lane4_acc(&fin, ptn, lh, ptn_freq[ptn]);
+    }
+    double tree_lh = lane4_sum(&fin);
+    if (isnan(tree_lh) || isinf(tree_lh)) {
+        tree_lh = 0.0;
+        for (size_t ptn = 0; ptn < nptn; ptn++) {
+            if (isnan(pattern_lh[ptn]) || isinf(pattern_lh[ptn]))
+                pattern_lh[ptn] = LOG_SCALING_THRESHOLD * 4;
+            tree_lh += pattern_lh[ptn] * ptn_freq[ptn];
+        }
+    }
+    free(val);
+    return tree_lh;
+}

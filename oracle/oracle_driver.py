@@ -1,0 +1,313 @@
+"""Python driver of the CPU oracle (oracle/lh_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product path (iq-tree_amd/).  It walks a tree the way
+PhyloTree::computeLikelihood does (phylotree.cpp:1031, phylokernel.h:70-157), calling the C
+restatement of the reference's pattern loops for every node, with everything in the
+reference's host layout.
+"""
+import ctypes as C
+import os
+import subprocess
+import time
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    src = os.path.join(_HERE, "lh_oracle.c")
+    out = os.path.join(_HERE, "liblh_oracle.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O3", "-mavx", "-ffp-contract=off", "-fPIC", "-shared",
+                               "-o", out, src, "-lm"])
+    return out
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    L = C.CDLL(build())
+    dp = C.POINTER(C.c_double)
+    u8 = C.POINTER(C.c_uint8)
+    sp = C.POINTER(C.c_short)
+    L.oracle_scaling_threshold.restype = C.c_double
+    L.oracle_log_scaling_threshold.restype = C.c_double
+    L.oracle_tip_partial_lh.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp]
+    L.oracle_tip_partial_lh.restype = None
+    L.oracle_echild.argtypes = [C.c_int, C.c_int, dp, dp, dp, C.c_double, dp]
+    L.oracle_echild.restype = None
+    L.oracle_partial_update.argtypes = [C.c_int, C.c_int, C.c_size_t, dp, dp, dp, dp, dp, C.c_int,
+                                        u8, dp, sp, C.c_double, u8, dp, sp, C.c_double, dp, dp, dp, sp]
+    L.oracle_partial_update.restype = C.c_double
+    L.oracle_branch_lnl.argtypes = [C.c_int, C.c_int, C.c_size_t, dp, dp, dp, C.c_double, dp, u8, dp, dp,
+                                    dp, dp, dp]
+    L.oracle_branch_lnl.restype = C.c_double
+    L.oracle_theta.argtypes = [C.c_int, C.c_int, C.c_size_t, dp, u8, dp, dp, dp]
+    L.oracle_theta.restype = None
+    L.oracle_derv.argtypes = [C.c_int, C.c_int, C.c_size_t, dp, dp, dp, C.c_double, dp, dp, dp, dp, dp]
+    L.oracle_derv.restype = None
+    L.oracle_lnl_from_theta.argtypes = [C.c_int, C.c_int, C.c_size_t, dp, dp, dp, C.c_double, dp, dp, dp, dp]
+    L.oracle_lnl_from_theta.restype = C.c_double
+    _LIB = L
+    return L
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _u8(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _sp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_short))
+
+
+SEQ_DNA, SEQ_PROTEIN, SEQ_CODON, SEQ_OTHER = 0, 1, 2, 3
+
+
+def state_unknown_for(nstates, seq_type):
+    if seq_type == SEQ_DNA and nstates == 4:
+        return 18
+    if seq_type == SEQ_PROTEIN and nstates == 20:
+        return 23
+    return nstates
+
+
+def _parse_newick(s):
+    pos = [0]
+
+    def node():
+        kids = []
+        if s[pos[0]] == "(":
+            pos[0] += 1
+            while True:
+                kids.append(node())
+                if s[pos[0]] == ",":
+                    pos[0] += 1
+                    continue
+                if s[pos[0]] == ")":
+                    pos[0] += 1
+                    break
+        b = pos[0]
+        while s[pos[0]] not in ":,();":
+            pos[0] += 1
+        label = s[b:pos[0]]
+        length = 0.0
+        if s[pos[0]] == ":":
+            pos[0] += 1
+            b = pos[0]
+            while s[pos[0]] not in ",();":
+                pos[0] += 1
+            length = float(s[b:pos[0]])
+        return (label, length, kids)
+
+    return node()
+
+
+class OracleTree:
+    """Unrooted tree + alignment + model; partial vectors cached per directed edge."""
+
+    def __init__(self, newick, nstates, seq_type, states, ptn_freq, ptn_invar, model):
+        self.L = lib()
+        self.n = nstates
+        self.seq_type = seq_type
+        self.states = np.ascontiguousarray(states, dtype=np.uint8)
+        self.ntaxa, self.nptn = self.states.shape
+        self.freq = np.ascontiguousarray(ptn_freq, dtype=np.float64)
+        self.invar = (np.zeros(self.nptn) if ptn_invar is None
+                      else np.ascontiguousarray(ptn_invar, dtype=np.float64))
+        self.set_model(model)
+        # adjacency: node ids as the host mirror assigns them (leaves = taxon id, internal nodes
+        # numbered from ntaxa in Newick pre-order)
+        self.adj = {}
+        top = _parse_newick(newick.strip().rstrip(";") + ";")
+        self.next_id = self.ntaxa
+
+        def build(nd):
+            label, _, kids = nd
+            if not kids:
+                i = int(label)
+                self.adj.setdefault(i, [])
+                return i
+            i = self.next_id
+            self.next_id += 1
+            self.adj[i] = []
+            for k in kids:
+                c = build(k)
+                self.connect(i, c, k[1])
+            return i
+
+        if len(top[2]) == 2:
+            a, b = top[2]
+            na, nb = build(a), build(b)
+            self.connect(na, nb, a[1] + b[1])
+        else:
+            build(top)
+        self.cache = {}
+
+    def connect(self, a, b, length):
+        self.adj[a].append([b, length])
+        self.adj[b].append([a, length])
+
+    def set_model(self, model):
+        self.model = model
+        self.ncat = len(model.rates)
+        self.block = self.n * self.ncat
+        self.su = state_unknown_for(self.n, self.seq_type)
+        self.eval = np.ascontiguousarray(model.eval, dtype=np.float64)
+        self.evec = np.ascontiguousarray(model.evec, dtype=np.float64)
+        self.inv_evec = np.ascontiguousarray(model.inv_evec, dtype=np.float64)
+        self.rates = np.ascontiguousarray(model.rates, dtype=np.float64)
+        self.props = np.ascontiguousarray(model.props, dtype=np.float64)
+        self.tip = np.zeros((self.su + 1) * self.n)
+        self.L.oracle_tip_partial_lh(self.n, self.seq_type, self.su, _dp(self.inv_evec), _dp(self.tip))
+        self.cache = {}
+
+    # ---- tree helpers
+    def is_leaf(self, v):
+        return len(self.adj[v]) == 1
+
+    def length(self, a, b):
+        for nb, ln in self.adj[a]:
+            if nb == b:
+                return ln
+        raise KeyError((a, b))
+
+    def set_length(self, a, b, length):
+        for e in self.adj[a]:
+            if e[0] == b:
+                e[1] = length
+        for e in self.adj[b]:
+            if e[0] == a:
+                e[1] = length
+        self.cache = {}
+
+    def clear(self):
+        self.cache = {}
+
+    def farthest_leaf(self, root=0):
+        """mtree.cpp:2052-2070 from the root leaf."""
+        import sys
+        sys.setrecursionlimit(100000)
+        height = {}
+
+        def go(node, dad):
+            if dad is not None and self.is_leaf(node):
+                height[node] = 0
+                return node
+            res = None
+            height[node] = 0
+            for nb, _ in self.adj[node]:
+                if nb == dad:
+                    continue
+                leaf = go(nb, node)
+                if height[node] < height[nb] + 1:
+                    height[node] = height[nb] + 1
+                    res = leaf
+            return res
+
+        return go(root, None)
+
+    # ---- kernels
+    def partial(self, frm, to):
+        """Vector of the subtree at `to` seen from `frm` (the neighbour frm->to).
+        Returns (plh[nptn,block], scale_num[nptn] int16, lh_scale_factor)."""
+        import sys
+        sys.setrecursionlimit(100000)
+        key = (frm, to)
+        if key in self.cache:
+            return self.cache[key]
+        assert not self.is_leaf(to)
+        kids = [(nb, ln) for nb, ln in self.adj[to] if nb != frm]
+        assert len(kids) == 2, "oracle handles bifurcating nodes only"
+        (l, ll), (r, rl) = kids
+        if not self.is_leaf(l) and self.is_leaf(r):
+            (l, ll), (r, rl) = (r, rl), (l, ll)
+        args_l = self._child(to, l)
+        args_r = self._child(to, r)
+        out = np.zeros((self.nptn, self.block))
+        sc = np.zeros(self.nptn, dtype=np.int16)
+        sum_scale = self.L.oracle_partial_update(
+            self.n, self.ncat, self.nptn, _dp(self.eval), _dp(self.evec), _dp(self.inv_evec),
+            _dp(self.rates), _dp(self.tip), self.su,
+            _u8(args_l[0]), _dp(args_l[1]), _sp(args_l[2]), ll,
+            _u8(args_r[0]), _dp(args_r[1]), _sp(args_r[2]), rl,
+            _dp(self.freq), _dp(self.invar), _dp(out), _sp(sc))
+        res = (out, sc, args_l[3] + args_r[3] + sum_scale)
+        self.cache[key] = res
+        return res
+
+    def _child(self, node, child):
+        if self.is_leaf(child):
+            return (self.states[child], None, None, 0.0)
+        plh, sc, sf = self.partial(node, child)
+        return (None, plh, sc, sf)
+
+    def _ends(self, a, b):
+        """(dad_states, dad_plh, node_plh, scale_factor_sum) with the leaf (if any) as dad."""
+        if self.is_leaf(b):
+            a, b = b, a
+        if self.is_leaf(a):
+            plh, _, sf = self.partial(a, b)
+            return self.states[a], None, plh, sf
+        pa, _, sfa = self.partial(b, a)
+        pb, _, sfb = self.partial(a, b)
+        return None, pa, pb, sfa + sfb
+
+    def branch_lnl(self, a, b, length=None):
+        ds, dp_, np_, sf = self._ends(a, b)
+        ln = self.length(a, b) if length is None else length
+        plh = np.zeros(self.nptn)
+        v = self.L.oracle_branch_lnl(self.n, self.ncat, self.nptn, _dp(self.eval), _dp(self.rates),
+                                     _dp(self.props), ln, _dp(self.tip), _u8(ds), _dp(dp_), _dp(np_),
+                                     _dp(self.freq), _dp(self.invar), _dp(plh))
+        return sf + v, plh
+
+    def likelihood(self, root=0):
+        """clearAllPartialLH(); computeLikelihood(): branch = farthest leaf's pendant branch."""
+        leaf = self.farthest_leaf(root)
+        nb = self.adj[leaf][0][0]
+        return self.branch_lnl(leaf, nb)[0], (leaf, nb)
+
+    def theta(self, a, b):
+        ds, dp_, np_, sf = self._ends(a, b)
+        th = np.zeros((self.nptn, self.block))
+        self.L.oracle_theta(self.n, self.ncat, self.nptn, _dp(self.tip), _u8(ds), _dp(dp_), _dp(np_), _dp(th))
+        return th, sf
+
+    def derv(self, a, b, length=None, theta=None):
+        if theta is None:
+            theta, _ = self.theta(a, b)
+        ln = self.length(a, b) if length is None else length
+        df, ddf = C.c_double(), C.c_double()
+        self.L.oracle_derv(self.n, self.ncat, self.nptn, _dp(self.eval), _dp(self.rates), _dp(self.props),
+                           ln, _dp(theta), _dp(self.freq), _dp(self.invar), C.byref(df), C.byref(ddf))
+        return df.value, ddf.value
+
+    def lnl_from_theta(self, a, b, length=None, theta=None, sf=None):
+        if theta is None:
+            theta, sf = self.theta(a, b)
+        ln = self.length(a, b) if length is None else length
+        plh = np.zeros(self.nptn)
+        v = self.L.oracle_lnl_from_theta(self.n, self.ncat, self.nptn, _dp(self.eval), _dp(self.rates),
+                                         _dp(self.props), ln, _dp(theta), _dp(self.freq), _dp(self.invar),
+                                         _dp(plh))
+        return sf + v, plh
+
+    def time_traversals(self, budget_s=15.0, min_reps=1):
+        """cpu_baseline: repeat {clear; full traversal; root lnL}; returns (M upd/s, reps, seconds)."""
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            self.clear()
+            self.likelihood()
+            reps += 1
+            dt = time.perf_counter() - t0
+            if reps >= min_reps and dt >= budget_s:
+                break
+        return reps * (self.ntaxa - 2) * self.nptn / dt / 1e6, reps, dt

@@ -1,0 +1,100 @@
+"""CPU tests of the oracle (oracle/lh_oracle.c): against an independent probability-space
+implementation (tests/textbook.py) and against its own invariants.  The reference itself holds
+no golden values for this path, and its likelihood translation units cannot be
+built here without its cmake-generated header, so these tests plus tests/test_vcl_probe.py are
+what pins the oracle ("parity unpinned" against reference execution)."""
+import numpy as np
+import pytest
+
+
+def _setup(synth, oracle, ntaxa, nsites, n, ncat, seed, seq_type, missing=0.0, pinvar=0.0, lo=0.02, hi=0.2):
+    if n == 4:
+        model = synth.gtr_model(alpha=0.9, ncat=ncat, pinvar=pinvar)
+    else:
+        model = synth.random_reversible_model(n, seed, alpha=0.9, ncat=ncat, pinvar=pinvar)
+    nwk = synth.random_tree_newick(ntaxa, seed, lo, hi)
+    su = oracle.state_unknown_for(n, seq_type)
+    st = synth.simulate_alignment(nwk, model, nsites, seed + 1, missing, su)
+    pat, freq = synth.compress_patterns(st)
+    invar = synth.ptn_invar_for(pat, model)
+    tree = oracle.OracleTree(nwk, n, seq_type, pat, freq, invar, model)
+    return model, nwk, pat, freq, invar, tree, su
+
+
+@pytest.mark.parametrize("n,ncat,seq_type", [(4, 4, 0), (4, 1, 0), (20, 4, 1), (64, 1, 2)])
+def test_oracle_matches_textbook(synth, oracle, n, ncat, seq_type):
+    import textbook
+    model, nwk, pat, freq, invar, tree, su = _setup(synth, oracle, 9, 60, n, ncat, 11 + n, seq_type, missing=0.1)
+    lnl, (a, b) = tree.likelihood()
+    site = textbook.site_log_likelihoods(tree.adj, pat, model, seq_type, su)
+    ref = float((site * freq).sum())
+    assert abs(lnl - ref) <= 1e-9 * abs(ref)
+    _, plh = tree.branch_lnl(a, b)
+    np.testing.assert_allclose(plh, site, rtol=1e-9, atol=1e-9)
+
+
+def test_oracle_dna_ambiguity_codes(synth, oracle):
+    import textbook
+    model, nwk, pat, freq, invar, tree, su = _setup(synth, oracle, 8, 40, 4, 4, 5, 0)
+    rng = np.random.default_rng(0)
+    pat = pat.copy()
+    mask = rng.random(pat.shape) < 0.3
+    pat[mask] = rng.integers(4, 19, mask.sum())  # IUPAC codes 4..17 and unknown 18
+    tree = oracle.OracleTree(nwk, 4, 0, pat, freq, None, model)
+    lnl, _ = tree.likelihood()
+    site = textbook.site_log_likelihoods(tree.adj, pat, model, 0, su)
+    assert abs(lnl - float((site * freq).sum())) <= 1e-9 * abs(lnl)
+
+
+def test_oracle_invariant_sites(synth, oracle):
+    import textbook
+    model, nwk, pat, freq, invar, tree, su = _setup(synth, oracle, 8, 200, 4, 4, 3, 0, pinvar=0.2, hi=0.05)
+    assert (invar > 0).any()
+    lnl, _ = tree.likelihood()
+    site = textbook.site_log_likelihoods(tree.adj, pat, model, 0, su)
+    # textbook gives the Gamma part with props summing to 1-pinvar; add the +I term
+    site = np.log(np.exp(site) + invar)
+    assert abs(lnl - float((site * freq).sum())) <= 1e-9 * abs(lnl)
+
+
+def test_oracle_lnl_is_branch_independent(synth, oracle):
+    """Pulley principle: the lnL is the same on every branch (leaf and internal forms)."""
+    model, nwk, pat, freq, invar, tree, su = _setup(synth, oracle, 10, 80, 4, 4, 7, 0, missing=0.05)
+    vals = []
+    for a in tree.adj:
+        for b, _ in tree.adj[a]:
+            if a < b:
+                vals.append(tree.branch_lnl(a, b)[0])
+    assert max(vals) - min(vals) <= 1e-9 * abs(vals[0])
+
+
+def test_oracle_scaling_counters(synth, oracle):
+    """Deep tree with long branches: scaling events happen, counters are cumulative, and the lnL
+    still agrees with the log-space textbook value."""
+    import textbook
+    model = synth.random_reversible_model(20, 3, alpha=0.9, ncat=4)
+    nwk = synth.random_tree_newick(160, 3, 0.3, 0.6, caterpillar=True)
+    st = synth.simulate_alignment(nwk, model, 24, 4)
+    pat, freq = synth.compress_patterns(st)
+    tree = oracle.OracleTree(nwk, 20, 1, pat, freq, None, model)
+    lnl, (a, b) = tree.likelihood()
+    _, sc, sf = tree.partial(a, b)
+    assert sc.max() >= 1 and sf < 0
+    np.testing.assert_allclose(sf, oracle.lib().oracle_log_scaling_threshold() * float((sc * freq).sum()),
+                               rtol=1e-12)
+    site = textbook.site_log_likelihoods(tree.adj, pat, model, 1, 23)
+    assert abs(lnl - float((site * freq).sum())) <= 1e-9 * abs(lnl)
+
+
+def test_oracle_derivatives_match_finite_differences(synth, oracle):
+    model, nwk, pat, freq, invar, tree, su = _setup(synth, oracle, 9, 120, 4, 4, 21, 0)
+    for (a, b) in [(0, tree.adj[0][0][0]), (tree.ntaxa, tree.adj[tree.ntaxa][0][0])]:
+        t = tree.length(a, b)
+        th, sf = tree.theta(a, b)
+        df, ddf = tree.derv(a, b, t, th)
+        h = 1e-5
+        f = lambda x: tree.lnl_from_theta(a, b, x, th, sf)[0]
+        np.testing.assert_allclose(df, (f(t + h) - f(t - h)) / (2 * h), rtol=1e-6)
+        np.testing.assert_allclose(ddf, (f(t + h) - 2 * f(t) + f(t - h)) / h ** 2, rtol=2e-4)
+        # K9 == K6 at the current length
+        assert abs(f(t) - tree.branch_lnl(a, b)[0]) <= 1e-10 * abs(f(t))

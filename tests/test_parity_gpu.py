@@ -1,0 +1,291 @@
+"""GPU parity: the HIP path (through the C ABI of include/iqhip.h, driven by the host mirror the
+way the reference's callers drive PhyloTree) against the CPU oracle on identical inputs.
+Tolerances: lnL <= 1e-9 relative here (north_star allows 1e-6); partial vectors 1e-10 relative
+to the vector's max; integer scaling counters bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LNL_RTOL = 1e-9
+
+
+def make_case(synth, oracle, pkg, ntaxa, nptn, n, ncat, seed, seq_type=0, missing=0.0, pinvar=0.0,
+              lo=0.02, hi=0.2, caterpillar=False, mem_mode=0):
+    if n == 4:
+        model = synth.gtr_model(alpha=0.9, ncat=ncat, pinvar=pinvar)
+    else:
+        model = synth.random_reversible_model(n, seed, alpha=0.9, ncat=ncat, pinvar=pinvar)
+    su = oracle.state_unknown_for(n, seq_type)
+    nwk = synth.random_tree_newick(ntaxa, seed, lo, hi, caterpillar)
+    st = synth.simulate_alignment(nwk, model, nptn, seed + 1, missing, su)
+    pat, freq = synth.compress_patterns(st)
+    invar = synth.ptn_invar_for(pat, model)
+    ot = oracle.OracleTree(nwk, n, seq_type, pat, freq, invar, model)
+    t = pkg.PhyloTree(nwk)
+    t.set_mem_mode(mem_mode)
+    t.set_alignment(n, seq_type, pat, freq, invar)
+    t.set_model(model)
+    t.set_likelihood_kernel(pkg.LK_EIGEN_HIP)
+    t.attach_engine(0)
+    return t, ot, model, pat, freq
+
+
+def check_all_vectors(t, ot):
+    """every computed neighbour: vector, scale_num (bit-exact) and lh_scale_factor."""
+    nchecked = 0
+    for a in range(t.num_nodes):
+        for b, _ in t.neighbors(a):
+            info = t.neighbor_info(a, b)
+            if ot.is_leaf(b) or not (info["computed"] & 1) or info["key"] == 0:
+                continue
+            plh, sc, sf = ot.partial(a, b)
+            got = t.fetch_partial(a, b)
+            scale = np.abs(plh).max(axis=1, keepdims=True)
+            np.testing.assert_allclose(got / scale, plh / scale, rtol=0, atol=1e-10)
+            assert np.array_equal(t.fetch_scale_num(a, b), sc)
+            assert abs(info["lh_scale_factor"] - sf) <= 1e-12 * max(1.0, abs(sf))
+            nchecked += 1
+    return nchecked
+
+
+@pytest.mark.parametrize("ncat", [1, 2, 3, 4, 5, 6, 8])
+def test_dna_full_traversal_all_ncat(pkg, synth, oracle, ncat):
+    t, ot, *_ = make_case(synth, oracle, pkg, 14, 700, 4, ncat, 100 + ncat, missing=0.05)
+    t.clear_all_partial_lh()
+    lnl = t.compute_likelihood()
+    ref, (a, b) = ot.likelihood()
+    assert t.current_branch() == (a, b)
+    assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+    assert check_all_vectors(t, ot) == 14 - 2
+    _, plh = ot.branch_lnl(a, b)
+    np.testing.assert_allclose(t.fetch_pattern_lh(), plh, rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize("nptn", [1, 63, 64, 65, 255, 257, 1000])
+def test_ragged_pattern_counts(pkg, synth, oracle, nptn):
+    """tile edges: nptn not a multiple of the 64-pattern tile / 256-pattern workgroup."""
+    model = synth.gtr_model()
+    nwk = synth.random_tree_newick(7, 5)
+    st = synth.simulate_alignment(nwk, model, max(nptn, 4), 9)[:, :nptn]
+    freq = np.arange(1, nptn + 1, dtype=np.float64)
+    ot = oracle.OracleTree(nwk, 4, 0, st, freq, None, model)
+    t = pkg.PhyloTree(nwk)
+    t.set_alignment(4, 0, st, freq)
+    t.set_model(model)
+    t.attach_engine(0)
+    lnl = t.compute_likelihood()
+    ref, _ = ot.likelihood()
+    assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+
+
+def test_ambiguity_codes_and_gaps(pkg, synth, oracle):
+    model = synth.gtr_model()
+    nwk = synth.random_tree_newick(10, 3)
+    st = synth.simulate_alignment(nwk, model, 500, 4)
+    rng = np.random.default_rng(1)
+    m = rng.random(st.shape) < 0.35
+    st[m] = rng.integers(4, 19, m.sum())
+    st[3, :] = 18  # an all-gap sequence
+    pat, freq = synth.compress_patterns(st)
+    ot = oracle.OracleTree(nwk, 4, 0, pat, freq, None, model)
+    t = pkg.PhyloTree(nwk)
+    t.set_alignment(4, 0, pat, freq)
+    t.set_model(model)
+    t.attach_engine(0)
+    lnl = t.compute_likelihood()
+    ref, _ = ot.likelihood()
+    assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+    check_all_vectors(t, ot)
+
+
+def test_invariant_sites(pkg, synth, oracle):
+    t, ot, *_ = make_case(synth, oracle, pkg, 9, 900, 4, 4, 77, pinvar=0.25, hi=0.06)
+    assert (ot.invar > 0).any()
+    lnl = t.compute_likelihood()
+    ref, _ = ot.likelihood()
+    assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+
+
+def test_scaling_counters_bit_exact_deep_tree(pkg, synth, oracle):
+    """400-taxon caterpillar with long branches: every pattern is rescaled, several times."""
+    t, ot, *_ = make_case(synth, oracle, pkg, 400, 300, 4, 4, 5, lo=0.4, hi=0.9, caterpillar=True)
+    lnl = t.compute_likelihood()
+    ref, (a, b) = ot.likelihood()
+    _, sc, sf = ot.partial(a, b)
+    assert sc.max() >= 2 and sf < 0
+    assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+    assert check_all_vectors(t, ot) == 400 - 2
+    # computePatternLikelihood-style host view (phylotree.cpp:1059-1069)
+    lnl2, plh = t.compute_likelihood(want_pattern_lh=True)
+    _, oplh = ot.branch_lnl(a, b)
+    np.testing.assert_allclose(plh, oplh + sc * oracle.lib().oracle_log_scaling_threshold(), rtol=1e-11)
+
+
+def test_lazy_recompute_and_reroot(pkg, synth, oracle):
+    """partials are cached; evaluating on other branches re-orients LM_PER_NODE buffers and
+    gives the same lnL (pulley principle), both leaf and internal branch forms."""
+    t, ot, *_ = make_case(synth, oracle, pkg, 12, 400, 4, 4, 31, missing=0.02)
+    ref, _ = ot.likelihood()
+    lnl = t.compute_likelihood()
+    n0 = t.num_partial_lh_computations
+    assert abs(t.compute_likelihood() - lnl) == 0.0          # nothing recomputed
+    assert t.last_plan() == []
+    for a in range(t.num_nodes):
+        for b, _ in t.neighbors(a):
+            v = t.compute_likelihood_branch(a, b)
+            assert abs(v - ref) <= LNL_RTOL * abs(ref), (a, b)
+            o, _ = ot.branch_lnl(a, b)
+            assert abs(v - o) <= LNL_RTOL * abs(ref)
+    assert t.num_partial_lh_computations > n0
+
+
+def test_all_branch_memory_mode(pkg, synth, oracle):
+    t, ot, *_ = make_case(synth, oracle, pkg, 11, 300, 4, 4, 41, mem_mode=1)
+    ref, _ = ot.likelihood()
+    for a in range(t.num_nodes):
+        for b, _ in t.neighbors(a):
+            v = t.compute_likelihood_branch(a, b)
+            assert abs(v - ref) <= LNL_RTOL * abs(ref)
+    assert check_all_vectors(t, ot) == 2 * (11 - 3) + 11  # every directed edge into an internal node
+
+
+def test_derivatives_and_from_buffer(pkg, synth, oracle):
+    t, ot, *_ = make_case(synth, oracle, pkg, 10, 800, 4, 4, 51, missing=0.03)
+    t.compute_likelihood()
+    for (a, b) in [(0, t.neighbors(0)[0][0]), (t.num_leaves, t.neighbors(t.num_leaves)[0][0]),
+                   (t.num_leaves + 2, t.neighbors(t.num_leaves + 2)[1][0])]:
+        t.reset_theta()
+        df, ddf = t.compute_likelihood_derv(a, b)
+        odf, oddf = ot.derv(a, b)
+        assert abs(df - odf) <= 1e-9 * max(1.0, abs(odf)) + 1e-12 * abs(oddf)
+        assert abs(ddf - oddf) <= 1e-9 * abs(oddf)
+        v = t.compute_likelihood_from_buffer()
+        o, _ = ot.lnl_from_theta(a, b)
+        assert abs(v - o) <= LNL_RTOL * abs(o)
+        # a Newton-style sequence of lengths re-uses theta (phylotree.cpp:2135)
+        for length in (0.01, 0.13, 1.7):
+            t.set_branch_length(a, b, length, clear_reverse=False)
+            t.lib.iqhost_reset_theta  # (theta stays valid: only the length changed)
+            # theta_computed was reset by set_branch_length in the mirror; recompute is harmless
+            df, ddf = t.compute_likelihood_derv(a, b)
+            odf, oddf = ot.derv(a, b, length)
+            assert abs(df - odf) <= 1e-9 * max(1.0, abs(odf)) + 1e-12 * abs(oddf)
+            assert abs(ddf - oddf) <= 1e-9 * abs(oddf)
+        ot.clear()
+        t.set_branch_length(a, b, ot.length(a, b), clear_reverse=True)
+
+
+def test_branch_length_change_invalidates_reverse_partials(pkg, synth, oracle):
+    t, ot, *_ = make_case(synth, oracle, pkg, 9, 300, 4, 4, 61)
+    t.compute_likelihood()
+    a = t.num_leaves + 1
+    b = t.neighbors(a)[0][0]
+    t.set_branch_length(a, b, 0.5, clear_reverse=True)
+    ot.set_length(a, b, 0.5)
+    t.clear_all_partial_lh()  # new current_it, as model optimisers do
+    lnl = t.compute_likelihood()
+    ref, _ = ot.likelihood()
+    assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+
+
+def test_branch_length_optimisation_increases_lnl(pkg, synth, oracle):
+    """hot loop 2: Newton-Raphson on every branch through computeLikelihoodDerv."""
+    t, ot, *_ = make_case(synth, oracle, pkg, 8, 600, 4, 4, 71)
+    start = t.compute_likelihood()
+    # perturb all lengths, then optimise
+    for a in range(t.num_nodes):
+        for b, _ in t.neighbors(a):
+            if a < b:
+                t.set_branch_length(a, b, 0.3, clear_reverse=False)
+    t.clear_all_partial_lh()
+    bad = t.compute_likelihood()
+    opt = t.optimize_all_branches(iterations=20, tolerance=1e-4)
+    assert opt > bad and opt >= start - 1e-6 * abs(start)
+    # the optimised tree's lnL agrees with the oracle evaluated on the optimised lengths
+    ot2 = oracle.OracleTree(t.tree_string(), 4, 0, ot.states, ot.freq, None, ot.model)
+    ref, _ = ot2.likelihood()
+    assert abs(opt - ref) <= 1e-8 * abs(ref)
+
+
+def test_c_abi_direct_ops_and_errors(pkg, synth, oracle):
+    """the raw ABI: explicit op list, key re-use, upload/fetch round trip, error statuses."""
+    lib = pkg.libiqhip()
+    model = synth.gtr_model()
+    nwk = "((0:0.1,1:0.2):0.05,2:0.3,(3:0.1,4:0.15):0.07);"
+    st = synth.simulate_alignment(nwk, model, 200, 3)
+    freq = np.ones(200)
+    ot = oracle.OracleTree(nwk, 4, 0, st, freq, None, model)
+    e = C.c_void_p()
+    assert lib.iqhip_create(C.byref(e), 0, 4, 4, 200, 5) == 0
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    # compute before inputs -> INVALID
+    ops = (pkg.NodeOp * 2)()
+    ops[0] = pkg.NodeOp(101, 0, 0, 0, 1, 0.1, 0.2)
+    ops[1] = pkg.NodeOp(102, 0, 0, 3, 4, 0.1, 0.15)
+    ss = np.zeros(2)
+    assert lib.iqhip_update_partials(e, ops, 2, dp(ss)) == 2
+    assert b"set_model" in lib.iqhip_last_error()
+    tip = ot.tip
+    assert lib.iqhip_set_model(e, dp(ot.eval), dp(ot.evec), dp(ot.inv_evec), dp(ot.rates), dp(ot.props), 18, dp(tip)) == 0
+    assert lib.iqhip_set_alignment(e, st.ctypes.data_as(C.POINTER(C.c_uint8)), dp(freq), dp(np.zeros(200))) == 0
+    assert lib.iqhip_update_partials(e, ops, 2, dp(ss)) == 0
+    lnl = C.c_double()
+    # root branch: internal(101) -- internal node 5 .. evaluate at leaf 2: needs vector of node 5 seen from 2
+    ops3 = (pkg.NodeOp * 1)()
+    ops3[0] = pkg.NodeOp(103, 101, 102, -1, -1, 0.05, 0.07)
+    assert lib.iqhip_traverse_lnl(e, ops3, 1, pkg.leaf_end(2), pkg.key_end(103), 0.3, dp(ss), C.byref(lnl)) == 0
+    ref, _ = ot.branch_lnl(2, 5)
+    assert abs(lnl.value - ref) <= LNL_RTOL * abs(ref)
+    # fetch / upload round trip under a new key
+    buf = np.zeros(200 * 16)
+    sc = np.zeros(200, dtype=np.int16)
+    assert lib.iqhip_fetch_partial(e, 103, dp(buf)) == 0
+    assert lib.iqhip_fetch_scale_num(e, 103, sc.ctypes.data_as(C.POINTER(C.c_int16))) == 0
+    np.testing.assert_allclose(buf.reshape(200, 16), ot.partial(2, 5)[0], rtol=1e-10, atol=1e-300)
+    assert lib.iqhip_upload_partial(e, 777, dp(buf), sc.ctypes.data_as(C.POINTER(C.c_int16))) == 0
+    lnl2 = C.c_double()
+    assert lib.iqhip_branch_lnl(e, pkg.leaf_end(2), pkg.key_end(777), 0.3, C.byref(lnl2)) == 0
+    assert lnl2.value == lnl.value
+    # errors: unknown key, bad leaf, two-leaf branch, negative length
+    assert lib.iqhip_branch_lnl(e, pkg.leaf_end(2), pkg.key_end(999), 0.3, C.byref(lnl2)) == 2
+    assert lib.iqhip_branch_lnl(e, pkg.leaf_end(9), pkg.key_end(103), 0.3, C.byref(lnl2)) == 2
+    assert lib.iqhip_branch_lnl(e, pkg.leaf_end(1), pkg.leaf_end(2), 0.3, C.byref(lnl2)) == 2
+    assert lib.iqhip_branch_lnl(e, pkg.leaf_end(2), pkg.key_end(103), -1.0, C.byref(lnl2)) == 2
+    assert lib.iqhip_derv(e, 0.1, C.byref(lnl2), C.byref(lnl2)) == 2  # theta not computed
+    # rekey / release
+    assert lib.iqhip_rekey(e, 777, 778) == 0
+    assert lib.iqhip_branch_lnl(e, pkg.leaf_end(2), pkg.key_end(778), 0.3, C.byref(lnl2)) == 0
+    assert lib.iqhip_release(e, 778) == 0
+    assert lib.iqhip_branch_lnl(e, pkg.leaf_end(2), pkg.key_end(778), 0.3, C.byref(lnl2)) == 2
+    lib.iqhip_destroy(e)
+
+
+def test_async_result_buffer_path(pkg, synth, oracle):
+    """what the multi-GPU bench uses: results left on the device in a caller-owned buffer."""
+    import torch
+    t, ot, *_ = make_case(synth, oracle, pkg, 9, 500, 4, 4, 81)
+    lib = pkg.libiqhip()
+    eng = t.engine
+    res = torch.zeros(64, dtype=torch.float64, device="cuda:0")
+    assert lib.iqhip_bind_result_buffer(eng, C.c_void_p(res.data_ptr()), 64) == 0
+    t.set_dry_run(True)
+    t.clear_all_partial_lh()
+    t.compute_likelihood()            # dry run: only to obtain the plan
+    plan = t.last_plan()
+    a, b = t.current_branch()
+    t.set_dry_run(False)
+    ops = (pkg.NodeOp * len(plan))()
+    for k, p in enumerate(plan):
+        ops[k] = pkg.NodeOp(p["dst_key"], p["left_key"], p["right_key"], p["left_leaf"], p["right_leaf"],
+                            p["left_len"], p["right_len"])
+    end_b = pkg.key_end(plan[-1]["dst_key"])
+    assert lib.iqhip_traverse_lnl_async(eng, ops, len(plan), pkg.leaf_end(a), end_b, ot.length(a, b)) == 0
+    assert lib.iqhip_synchronize(eng) == 0
+    out = res.cpu().numpy()
+    ref, _ = ot.likelihood()
+    total = out[0] + out[2:2 + len(plan)].sum()
+    assert abs(total - ref) <= LNL_RTOL * abs(ref)
+    assert lib.iqhip_bind_result_buffer(eng, None, 0) == 0
