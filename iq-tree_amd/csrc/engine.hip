@@ -2,6 +2,7 @@
 // extern "C" entry points declared in include/iqhip.h.  There is NO CPU fallback in this
 // library: every compute entry point launches HIP kernels or fails with a status.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -71,6 +72,15 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
         return fail(IQHIP_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(s));
     }
     e->own_stream = true;
+    if (const char *ab = getenv("IQHIP_ABLATE")) e->ablate = atoi(ab);
+    if (const char *kb = getenv("IQHIP_LDS_KB")) {
+        int v = atoi(kb);
+        if (v >= 8 && v <= 150) e->lds_budget_bytes = v * 1024;
+    }
+    if (const char *wg = getenv("IQHIP_WG")) {
+        int v = atoi(wg);
+        if (v == 64 || v == 128 || v == 256) e->wg_size = v;
+    }
 
     const size_t P = (size_t)e->nptn_pad;
     bool ok = dmalloc(&e->d_states, (size_t)ntaxa * P) == hipSuccess &&
@@ -90,6 +100,13 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
         iqhip_destroy(e);
         return fail(IQHIP_ERR_NOMEM, "iqhip_create: device allocation failed");
     }
+    ok = dmalloc(&e->dummy.plh, P * e->block) == hipSuccess && dmalloc(&e->dummy.sc, P) == hipSuccess;
+    if (!ok) {
+        iqhip_destroy(e);
+        return fail(IQHIP_ERR_NOMEM, "iqhip_create: device allocation failed");
+    }
+    hipMemsetAsync(e->dummy.plh, 0, P * e->block * sizeof(double), e->stream);
+    hipMemsetAsync(e->dummy.sc, 0, P * sizeof(int16_t), e->stream);
     e->d_result = e->d_result_own;
     hipMemsetAsync(e->d_theta, 0, P * e->block * sizeof(double), e->stream);
     hipMemsetAsync(e->d_pattern_lh, 0, P * sizeof(double), e->stream);
@@ -109,7 +126,7 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
     }
     void *ptrs[] = {e->d_states, e->d_freq, e->d_invar, e->d_eval, e->d_evec, e->d_inv_evec,
                     e->d_rates, e->d_props, e->d_tip, e->d_ops, e->d_opmat, e->d_val, e->d_slab,
-                    e->d_theta, e->d_pattern_lh, e->d_result_own};
+                    e->d_theta, e->d_pattern_lh, e->d_result_own, e->dummy.plh, e->dummy.sc};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (e->h_ops) hipHostFree(e->h_ops);
@@ -288,17 +305,15 @@ extern "C" int iqhip_set_model(iqhip_engine *e, const double *eval, const double
 // plan building
 // ---------------------------------------------------------------------------------------
 static int ensure_plan_capacity(iqhip_engine *e, int nops) {
-    if (nops > e->result_cap - 2)
+    if (nops > e->result_cap - 1)
         return fail(IQHIP_ERR_INVALID, "too many node updates in one submission");
     if (nops <= e->ops_cap) return IQHIP_OK;
     HIPCHK(hipStreamSynchronize(e->stream));
     int cap = std::max(64, nops * 2);
     if (e->d_ops) hipFree(e->d_ops);
-    if (e->d_opmat) hipFree(e->d_opmat);
     if (e->h_ops) hipHostFree(e->h_ops);
-    e->d_ops = nullptr; e->d_opmat = nullptr; e->h_ops = nullptr; e->ops_cap = 0;
+    e->d_ops = nullptr; e->h_ops = nullptr; e->ops_cap = 0;
     HIPCHK(dmalloc(&e->d_ops, cap));
-    HIPCHK(dmalloc(&e->d_opmat, (size_t)cap * 2 * e->ncat * e->n * e->n));
     HIPCHK(hipHostMalloc((void **)&e->h_ops, sizeof(DevOp) * cap));
     e->ops_cap = cap;
     return IQHIP_OK;
@@ -346,43 +361,96 @@ static int resolve_child(iqhip_engine *e, uint64_t key, int32_t leaf, int prev_d
 }
 
 static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *last_dst) {
-    int rc = ensure_plan_capacity(e, nops);
+    int rc = ensure_plan_capacity(e, nops + 1);  // + sentinel
     if (rc) return rc;
     if (e->staging_busy) {  // the previous submission may still be copying h_ops
         HIPCHK(hipEventSynchronize(e->staging_free));
         e->staging_busy = false;
     }
     int prev_dst = -1;
+    const int B = e->block;
+    e->plan_has_load = false;
+    auto dummy_op = [&](DevOp &d) {
+        memset(&d, 0, sizeof(d));
+        d.dst = e->dummy.plh;
+        d.dst_sc = e->dummy.sc;
+        d.pf = d.ld = e->dummy.plh;
+        d.pf_sc = d.ld_sc = e->dummy.sc;
+        d.sl = d.sr = e->d_states;
+    };
     for (int k = 0; k < nops; k++) {
         const iqhip_node_op &o = ops[k];
         DevOp &d = e->h_ops[k];
+        dummy_op(d);
         if (!(o.left_len >= 0.0) || !(o.right_len >= 0.0))
             return fail(IQHIP_ERR_INVALID, "negative or NaN branch length");
-        rc = resolve_child(e, o.left_key, o.left_leaf, prev_dst, &d.left, &d.left_sc, &d.left_states,
-                           &d.left_kind);
+        const double *lp, *rp;
+        const int16_t *lsc, *rsc;
+        const uint8_t *lst, *rst;
+        int32_t lkind, rkind;
+        rc = resolve_child(e, o.left_key, o.left_leaf, prev_dst, &lp, &lsc, &lst, &lkind);
         if (rc) return rc;
-        rc = resolve_child(e, o.right_key, o.right_leaf, prev_dst, &d.right, &d.right_sc,
-                           &d.right_states, &d.right_kind);
+        rc = resolve_child(e, o.right_key, o.right_leaf, prev_dst, &rp, &rsc, &rst, &rkind);
         if (rc) return rc;
         int didx;
         rc = slab_for_key(e, o.dst_key, true, &didx);
         if (rc) return rc;
-        if ((d.left_kind != CHILD_LEAF && d.left == e->slabs[didx].plh) ||
-            (d.right_kind != CHILD_LEAF && d.right == e->slabs[didx].plh))
+        if ((lkind != CHILD_LEAF && lp == e->slabs[didx].plh) || (rkind != CHILD_LEAF && rp == e->slabs[didx].plh))
             return fail(IQHIP_ERR_INVALID, "node update writes onto one of its own children");
+        if (lkind == CHILD_PREV && rkind == CHILD_PREV)
+            return fail(IQHIP_ERR_INVALID, "node update uses the same vector for both children");
+        // canonical form (the Hadamard product commutes): left in {LEAF, PF}, right in
+        // {LEAF, PREV}; the only other shape is (PF, LOAD): two memory children, neither of
+        // them the previous result -- the kernel reads the second one synchronously.
+        double llen = o.left_len, rlen = o.right_len;
+        auto swap_children = [&]() {
+            std::swap(lp, rp); std::swap(lsc, rsc); std::swap(lst, rst);
+            std::swap(lkind, rkind); std::swap(llen, rlen);
+        };
+        if (lkind == CHILD_PREV) swap_children();                              // PREV goes right
+        else if (lkind == CHILD_LEAF && rkind == CHILD_LOAD) swap_children();  // memory child goes left
+        if (lkind == CHILD_LOAD) lkind = CHILD_PF;
+        if (rkind == CHILD_LOAD) e->plan_has_load = true;                      // (PF, LOAD)
         d.dst = e->slabs[didx].plh;
         d.dst_sc = e->slabs[didx].sc;
-        d.left_len = o.left_len;
-        d.right_len = o.right_len;
+        if (lkind == CHILD_PF) { d.pf = lp; d.pf_sc = lsc; d.real_mask |= 1; }
+        if (rkind == CHILD_LOAD) { d.ld = rp; d.ld_sc = rsc; }
+        if (lkind == CHILD_LEAF) { d.sl = lst; d.real_mask |= 2; }
+        if (rkind == CHILD_LEAF) { d.sr = rst; d.real_mask |= 4; }
+        if (e->ablate & 1) d.real_mask &= ~1;  // timing-only: never stream a child (results wrong)
+        if (e->ablate & 2) d.real_mask &= ~6;  // timing-only: never read leaf states
+        d.left_kind = lkind;
+        d.right_kind = rkind;
+        d.left_len = llen;
+        d.right_len = rlen;
         prev_dst = didx;
     }
+    dummy_op(e->h_ops[nops]);  // sentinel: target of the last op's unconditional prefetch
     *last_dst = prev_dst;
-    if (nops > 0) {
-        HIPCHK(hipMemcpyAsync(e->d_ops, e->h_ops, sizeof(DevOp) * nops, hipMemcpyHostToDevice,
-                              e->stream));
-        HIPCHK(hipEventRecord(e->staging_free, e->stream));
-        e->staging_busy = true;
+    // LDS layout of the per-(op, child) regions, cut into chunks that fit the budget
+    {
+        const int budget = (e->lds_budget_bytes / 8) - 128 - B;
+        int chunk_start = 0, used = 0, max_used = 0;
+        for (int k = 0; k < nops; k++) {
+            DevOp &d = e->h_ops[k];
+            const int need = (d.left_kind == CHILD_LEAF ? 6 * B : B) + (d.right_kind == CHILD_LEAF ? 6 * B : B);
+            if (used + need > budget && k > chunk_start) {
+                e->h_ops[chunk_start].chunk_nops = k - chunk_start;
+                chunk_start = k;
+                used = 0;
+            }
+            d.lds_left = used;
+            d.lds_right = used + (d.left_kind == CHILD_LEAF ? 6 * B : B);
+            used += need;
+            if (used > max_used) max_used = used;
+        }
+        if (nops > 0) e->h_ops[chunk_start].chunk_nops = nops - chunk_start;
+        e->plan_lds_doubles = max_used;
     }
+    HIPCHK(hipMemcpyAsync(e->d_ops, e->h_ops, sizeof(DevOp) * (nops + 1), hipMemcpyHostToDevice,
+                          e->stream));
+    HIPCHK(hipEventRecord(e->staging_free, e->stream));
+    e->staging_busy = true;
     return IQHIP_OK;
 }
 
@@ -435,7 +503,6 @@ static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, 
     rc = ensure_slab_rows(e, 2 + nops);
     if (rc) return rc;
     const int nwaves = (int)e->ntiles;
-    HIPCHK(launch_echild(e, nops));
     timing_begin(e);
     HIPCHK(launch_traverse4(e, nops, has_root ? &br : nullptr, nwaves));
     timing_end(e);

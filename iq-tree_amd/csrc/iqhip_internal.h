@@ -23,23 +23,29 @@ constexpr double kScalingThresholdInv = 0x1p256;     // phylotree.h:51
 // log(2^-256) as libm returns it (phylotree.h:53)
 constexpr double kLogScalingThreshold = -177.44567822334599;
 
-enum ChildKind : int32_t { CHILD_LEAF = 0, CHILD_LOAD = 1, CHILD_PREV = 2 };
+// LEAF: state bytes; LOAD: read now; PREV: previous op's result (registers);
+// PF: read one op ahead into the prefetch registers
+enum ChildKind : int32_t { CHILD_LEAF = 0, CHILD_LOAD = 1, CHILD_PREV = 2, CHILD_PF = 3 };
 
 // One node update as the device sees it. 16-byte aligned so that the wave-uniform reads
 // of the descriptor become scalar loads.
 struct __attribute__((aligned(16))) DevOp {
     double *dst;
     int16_t *dst_sc;
-    const double *left;
-    const int16_t *left_sc;
-    const uint8_t *left_states;
-    const double *right;
-    const int16_t *right_sc;
-    const uint8_t *right_states;
+    const double *pf;        // the streamed child (kind CHILD_PF) or the engine's dummy slab
+    const int16_t *pf_sc;    // its scale counters (or dummy)
+    const uint8_t *sl;       // state row of a LEAF left child (or a dummy row)
+    const uint8_t *sr;       // ... right child
+    const double *ld;        // second memory child (kind CHILD_LOAD, right only), else dummy
+    const int16_t *ld_sc;
     int32_t left_kind;
     int32_t right_kind;
     double left_len;
     double right_len;
+    int32_t lds_left;   // offset (doubles) of the child's LDS region inside the chunk:
+    int32_t lds_right;  //   internal child: [ex B]; leaf child: [ex B][table 5B]
+    int32_t chunk_nops; // > 0 on the first op of an LDS chunk: number of ops in the chunk
+    int32_t real_mask;  // bit0: pf/pf_sc are real, bit1: sl is real, bit2: sr is real (else dummies)
 };
 
 // Root branch descriptor for the lnL / theta kernels.
@@ -66,6 +72,12 @@ struct iqhip_engine {
     int64_t nptn_pad = 0;  // padded to the tile size
     int64_t ntiles = 0;    // tiles of `tile` patterns
     int tile = 64;         // 64 (VALU path) or 16 (MFMA path)
+    int wg_size = 256;     // threads per workgroup of the traversal kernel (IQHIP_WG env)
+    int ablate = 0;        // IQHIP_ABLATE: timing-only host-side switches (results wrong when set)
+    int lds_budget_bytes = 64 * 1024;  // per-workgroup LDS for the per-branch regions (IQHIP_LDS_KB)
+    int plan_lds_doubles = 0;
+    bool plan_has_load = false;  // some op has two memory children (slow kernel instantiation)
+    iqhip::Slab dummy;           // valid target of unconditional prefetches  // LDS region size (doubles) of the largest chunk of the current plan
     int block = 0;         // n*ncat
     int state_unknown = -1;
     bool model_set = false, aln_set = false, theta_valid = false;

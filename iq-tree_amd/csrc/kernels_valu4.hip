@@ -84,10 +84,27 @@ __device__ __forceinline__ void store_vec4(double *__restrict__ base, int64_t ti
 
 // ---------------------------------------------------------------------------------------
 // the fused traversal kernel
+//
+// Each wave walks the whole op list for its 64 patterns, so the list is a chain of nops
+// dependent steps.  Ablation on MI355X (profiles/r01/ablation_v2.txt) showed the chain to be
+// instruction-ISSUE bound, not memory bound (removing every load and store changed nothing),
+// so the body is built to issue as little as possible per step:
+//   * per-branch uniform data is reduced to the exponentials ex[c][i] = exp(eval_i r_c t)
+//     (E = U*diag(ex), phylokernel.h:159-181, so E*v = U*(ex .* v)), computed by the workgroup
+//     itself into LDS once per launch (no K1 launch, no matrix traffic) and read back as
+//     broadcast ds_read; U and U^-1 are op-invariant scalar (SGPR) operands;
+//   * a LEAF child is the reference's K2 lookup (phylokernel.h:187-232,293-317): a 5-row table
+//     (A,C,G,T,unknown -- the unknown row exactly 1.0) built in LDS per (op, leaf child) with
+//     the reference's own unfused association, read with the lane's state as row index; IUPAC
+//     ambiguity codes take a wave-uniform slow path that evaluates E*tip on the fly;
+//   * the body is specialised at compile time on the kind of each child (LEAF / PREV / PF):
+//     the previous result is consumed in place in its registers, no copies, no selects;
+//   * the one child of op k+1 that has to come from memory (CHILD_PF), its scale counter and
+//     the leaf state bytes are requested while op k computes.
 // ---------------------------------------------------------------------------------------
 struct Trav4Args {
     const DevOp *ops;
-    const double *opmat;
+    const double *evec;
     const double *inv_evec;
     const double *tip;
     const double *freq;
@@ -106,130 +123,269 @@ struct Trav4Args {
     DevBranch root;
 };
 
+// a[x] (x = 0..3) of a LEAF child for category c: table row (fast path) or E*tip evaluated on
+// the fly when some lane of the wave holds an IUPAC ambiguity code (slow, wave-uniform)
 template <int C>
-__global__ __launch_bounds__(256) void k_traverse4(const Trav4Args A) {
+__device__ __forceinline__ void leaf_cat4(const double *reg /* [ex B][table 5B] */, const double *s_tip,
+                                          const CONST_AS double *U, int s, int row, bool slow,
+                                          int state_unknown, int c, double (&a)[4]) {
     constexpr int B = 4 * C;
-    __shared__ double s_tip[32 * 4];  // tip_partial_lh rows, state_unknown <= 31
-    __shared__ double s_val[B];       // root-branch val[c][i]
+    if (__builtin_expect(slow, 0)) {
+        double l[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) l[i] = reg[c * 4 + i] * s_tip[s * 4 + i];
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            double v = U[x * 4] * l[0];
+            v = fma(U[x * 4 + 1], l[1], v);
+            v = fma(U[x * 4 + 2], l[2], v);
+            v = fma(U[x * 4 + 3], l[3], v);
+            a[x] = (s == state_unknown) ? 1.0 : v;
+        }
+    } else {
+        const double2 *tab = reinterpret_cast<const double2 *>(reg + B + row * B + c * 4);
+        const double2 v0 = tab[0], v1 = tab[1];
+        a[0] = v0.x; a[1] = v0.y; a[2] = v1.x; a[3] = v1.y;
+    }
+}
+
+// One node update.  The host canonicalises every op (the Hadamard product commutes) so that
+//   left  is a LEAF or the streamed child held in the PF registers (CHILD_PF), and
+//   right is a LEAF or the previous result held in `prev`            (CHILD_PREV),
+// which leaves two independent wave-uniform two-way choices instead of a kind x kind product.
+// `prev` is read in place and receives the new vector.  The PF registers are consumed category
+// by category; right after category c has been read the same registers are re-targeted at
+// op k+1's streamed child (nx_pf), so the prefetch needs no second register set and no copy.
+// Returns lh_max (0 for LEAF-LEAF, which the reference never rescales).
+template <int C>
+__device__ __forceinline__ double node_update4(bool leafL, bool leafR, const double *regL,
+                                               const double *regR, const double *s_tip,
+                                               const CONST_AS double *U, const CONST_AS double *uinv,
+                                               int sL, int sR, int state_unknown, const char *nx_pf,
+                                               double (&PF)[4 * C], double (&prev)[4 * C]) {
+    bool slowL = false, slowR = false;
+    int rowL = 0, rowR = 0;
+    if (leafL) {
+        slowL = __any((sL >= 4) && (sL != state_unknown));
+        rowL = sL < 4 ? sL : 4;
+    }
+    if (leafR) {
+        slowR = __any((sR >= 4) && (sR != state_unknown));
+        rowR = sR < 4 ? sR : 4;
+    }
+    double lh_max = 0.0;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        double a[4], b[4], tmp[4];
+        if (leafL) {
+            leaf_cat4<C>(regL, s_tip, U, sL, rowL, slowL, state_unknown, c, a);
+        } else {
+            double l[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) l[i] = regL[c * 4 + i] * PF[c * 4 + i];
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                double v = U[x * 4] * l[0];
+                v = fma(U[x * 4 + 1], l[1], v);
+                v = fma(U[x * 4 + 2], l[2], v);
+                a[x] = fma(U[x * 4 + 3], l[3], v);
+            }
+        }
+        // category c of PF is dead now: stream in the same slice of op k+1's memory child
+        {
+            const double2 t0 = *reinterpret_cast<const double2 *>(nx_pf + (2 * c) * 1024);
+            const double2 t1 = *reinterpret_cast<const double2 *>(nx_pf + (2 * c + 1) * 1024);
+            PF[c * 4] = t0.x; PF[c * 4 + 1] = t0.y; PF[c * 4 + 2] = t1.x; PF[c * 4 + 3] = t1.y;
+        }
+        if (leafR) {
+            leaf_cat4<C>(regR, s_tip, U, sR, rowR, slowR, state_unknown, c, b);
+        } else {
+            double r[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) r[i] = regR[c * 4 + i] * prev[c * 4 + i];
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                double v = U[x * 4] * r[0];
+                v = fma(U[x * 4 + 1], r[1], v);
+                v = fma(U[x * 4 + 2], r[2], v);
+                b[x] = fma(U[x * 4 + 3], r[3], v);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++) tmp[x] = a[x] * b[x];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            double o = uinv[i * 4] * tmp[0];
+            o = fma(uinv[i * 4 + 1], tmp[1], o);
+            o = fma(uinv[i * 4 + 2], tmp[2], o);
+            o = fma(uinv[i * 4 + 3], tmp[3], o);
+            prev[c * 4 + i] = o;
+            lh_max = fmax(lh_max, fabs(o));
+        }
+    }
+    return (leafL && leafR) ? 0.0 : lh_max;
+}
+
+// byte-offset addressing: a wave-uniform base (SGPR pair) plus one per-lane 32-bit offset that
+// is computed once per kernel, so no per-op VALU goes into addresses
+template <int C>
+__device__ __forceinline__ void load_vec4_off(const double *base, uint32_t voff, double (&v)[4 * C]) {
+    const char *p = reinterpret_cast<const char *>(base) + voff;
+#pragma unroll
+    for (int j = 0; j < 2 * C; j++) {
+        const double2 t = *reinterpret_cast<const double2 *>(p + j * 1024);
+        v[2 * j] = t.x;
+        v[2 * j + 1] = t.y;
+    }
+}
+template <int C>
+__device__ __forceinline__ void store_vec4_off(double *base, uint32_t voff, const double (&v)[4 * C]) {
+    char *p = reinterpret_cast<char *>(base) + voff;
+#pragma unroll
+    for (int j = 0; j < 2 * C; j++)
+        *reinterpret_cast<double2 *>(p + j * 1024) = make_double2(v[2 * j], v[2 * j + 1]);
+}
+
+// HAS_LOAD: the plan contains an op with two memory children (the second one is CHILD_LOAD and
+// is read synchronously); the fast instantiation has no such path, so that the VMEM sequence
+// of a loop iteration is the same on every path and the compiler can use counted vmcnt waits
+// (stores of op k-1 stay in flight while op k computes).
+template <int C, int WG, bool HAS_LOAD>
+__global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
+    constexpr int B = 4 * C;
+    constexpr int WPB = WG / 64;  // waves (= 64-pattern tiles) per block
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *s_tip = smem;             // [32][4]
+    double *s_val = smem + 128;       // [B]
+    double *s_reg = smem + 128 + B;   // per (op, child) regions of the current chunk
 
     const int nst = A.state_unknown + 1;
-    for (int t = threadIdx.x; t < nst * 4; t += 256) s_tip[t] = A.tip[t];
+    for (int t = threadIdx.x; t < nst * 4; t += WG) s_tip[t] = A.tip[t];
     if (A.has_root && threadIdx.x < B) {
         const int c = threadIdx.x >> 2, i = threadIdx.x & 3;
         s_val[threadIdx.x] = exp(A.eval[i] * (A.rates[c] * A.root.len)) * A.props[c];
     }
-    __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= A.ntiles) return;  // wave-uniform; no barrier below
-    const int gw = (int)tile;      // global wave id == tile id
-    const int64_t ptn = tile * 64 + lane;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // make it provably uniform
+    const int64_t tile = (int64_t)blockIdx.x * WPB + wave;
+    const bool active = tile < A.ntiles;
+    const int64_t tl = active ? tile : 0;
+    const int gw = (int)tl;               // global wave id == tile id
+    const int64_t ptn = tl * 64 + lane;
+    const uint32_t voff = (uint32_t)(tl * (64 * B * 8) + lane * 16);  // bytes into a vector slab
+    const uint32_t soff = (uint32_t)(ptn * 2);                        // bytes into a scale array
+    const uint32_t poff = (uint32_t)ptn;                              // bytes into a state row
 
     const double freq = A.freq[ptn];
     const double invar = A.invar[ptn];
 
+    const CONST_AS double *U = as_const(A.evec);
     const CONST_AS double *uinv = as_const(A.inv_evec);
-    double prev[B];
-#pragma unroll
-    for (int e = 0; e < B; e++) prev[e] = 0.0;
+    const CONST_AS DevOp *ops = as_const(A.ops);
 
-    for (int k = 0; k < A.nops; k++) {
-        const CONST_AS DevOp *op = as_const(A.ops) + k;
-        const int lk = op->left_kind, rk = op->right_kind;
-        double L[B], R[B];
-        bool unkL = false, unkR = false;
-        int sc = 0;
-        // ---- left child
-        if (lk == CHILD_LEAF) {
-            const int s = op->left_states[ptn];
-            unkL = (s == A.state_unknown);
+    double prev[B], PF[B];
+    int pf_sc = 0, prev_sc = 0, nsL = 0, nsR = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const double t = s_tip[s * 4 + i];
-#pragma unroll
-                for (int c = 0; c < C; c++) L[c * 4 + i] = t;
-            }
-        } else {
-            if (lk == CHILD_PREV) {
-#pragma unroll
-                for (int e = 0; e < B; e++) L[e] = prev[e];
-            } else {
-                load_vec4<C>(op->left, tile, lane, L);
-            }
-            sc += op->left_sc[ptn];
-        }
-        // ---- right child
-        if (rk == CHILD_LEAF) {
-            const int s = op->right_states[ptn];
-            unkR = (s == A.state_unknown);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const double t = s_tip[s * 4 + i];
-#pragma unroll
-                for (int c = 0; c < C; c++) R[c * 4 + i] = t;
-            }
-        } else {
-            if (rk == CHILD_PREV) {
-#pragma unroll
-                for (int e = 0; e < B; e++) R[e] = prev[e];
-            } else {
-                load_vec4<C>(op->right, tile, lane, R);
-            }
-            sc += op->right_sc[ptn];
-        }
-        // ---- out[c] = U^-1 * ((E_L[c]*L[c]) .* (E_R[c]*R[c]))   phylokernel.h:420-459
-        const CONST_AS double *EL = as_const(A.opmat) + (size_t)k * (2 * C * 16);
-        const CONST_AS double *ER = EL + C * 16;
-        double lh_max = 0.0;
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            double tmp[4];
-#pragma unroll
-            for (int x = 0; x < 4; x++) {
-                const CONST_AS double *el = EL + c * 16 + x * 4;
-                const CONST_AS double *er = ER + c * 16 + x * 4;
-                double a = el[0] * L[c * 4];
-                a = fma(el[1], L[c * 4 + 1], a);
-                a = fma(el[2], L[c * 4 + 2], a);
-                a = fma(el[3], L[c * 4 + 3], a);
-                double b = er[0] * R[c * 4];
-                b = fma(er[1], R[c * 4 + 1], b);
-                b = fma(er[2], R[c * 4 + 2], b);
-                b = fma(er[3], R[c * 4 + 3], b);
-                // the reference's lookup row for STATE_UNKNOWN is exactly 1.0 (:228-232)
-                a = unkL ? 1.0 : a;
-                b = unkR ? 1.0 : b;
-                tmp[x] = a * b;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                double r = uinv[i * 4] * tmp[0];
-                r = fma(uinv[i * 4 + 1], tmp[1], r);
-                r = fma(uinv[i * 4 + 2], tmp[2], r);
-                r = fma(uinv[i * 4 + 3], tmp[3], r);
-                prev[c * 4 + i] = r;
-                lh_max = fmax(lh_max, fabs(r));
-            }
-        }
-        // ---- scaling (SIMD rule, phylokernel.h:379-392,461-474); TIP-TIP never scales
-        const bool both_leaf = (lk == CHILD_LEAF) && (rk == CHILD_LEAF);
-        const bool do_scale = !both_leaf && (lh_max < kScalingThreshold) && (invar == 0.0);
-        double my_scale = 0.0;
-        if (do_scale) {
-#pragma unroll
-            for (int e = 0; e < B; e++) prev[e] *= kScalingThresholdInv;
-            sc += 1;
-            my_scale = (ptn < A.nptn) ? kLogScalingThreshold * freq : 0.0;
-        }
-        store_vec4<C>(op->dst, tile, lane, prev);
-        op->dst_sc[ptn] = (int16_t)sc;
-        // deterministic reduction: wave partial -> slab[2+k][gw]
-        const unsigned long long any = __ballot(do_scale);
-        double ws = 0.0;
-        if (any) ws = wave_sum(my_scale);
-        if (lane == 0) A.slab[(size_t)(2 + k) * A.nwaves + gw] = ws;
+    for (int e = 0; e < B; e++) { prev[e] = 0.0; PF[e] = 0.0; }
+
+    // everything op k needs from memory is requested while op k-1 computes.  Prime for op 0.
+    // (ops[nops] is a sentinel whose pointers are valid dummies, so the requests are unconditional)
+    if (active) {
+        const CONST_AS DevOp *nx = ops;
+        const int nreal = nx->real_mask;
+        load_vec4_off<C>(nx->pf, (nreal & 1) ? voff : (uint32_t)(lane * 16), PF);
+        pf_sc = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(nx->pf_sc) +
+                                                   ((nreal & 1) ? soff : (uint32_t)(lane * 2)));
+        nsL = *(nx->sl + ((nreal & 2) ? poff : (uint32_t)lane));
+        nsR = *(nx->sr + ((nreal & 4) ? poff : (uint32_t)lane));
     }
+
+    int k = 0;
+    while (k < A.nops) {
+        // ---- fill the LDS regions of the chunk that starts at op k (host-chosen boundaries)
+        const int kn = ops[k].chunk_nops;
+        __syncthreads();  // the previous chunk's regions are no longer read
+        for (int t = threadIdx.x; t < kn * 2 * B; t += WG) {  // phase 1: exponentials
+            const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B;
+            const DevOp &d = A.ops[k + o];
+            const double len = child ? d.right_len : d.left_len;
+            s_reg[(child ? d.lds_right : d.lds_left) + e] = exp(A.eval[e & 3] * (A.rates[e >> 2] * len));
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < kn * 2 * 5 * B; t += WG) {  // phase 2: leaf tables (K2)
+            const int o = t / (10 * B), r = t - o * (10 * B), child = r / (5 * B), q = r - child * (5 * B);
+            const DevOp &d = A.ops[k + o];
+            if ((child ? d.right_kind : d.left_kind) != CHILD_LEAF) continue;
+            const int row = q / B, e = q - row * B, c = e >> 2, x = e & 3;
+            double *reg = s_reg + (child ? d.lds_right : d.lds_left);
+            double v = 1.0;  // STATE_UNKNOWN row (phylokernel.h:228-232)
+            if (row < 4) {
+                // E = U*ex rounded first, then the reference's (t0+t1)+(t2+t3), all unfused
+                const double e0 = __dmul_rn(A.evec[x * 4 + 0], reg[c * 4 + 0]);
+                const double e1 = __dmul_rn(A.evec[x * 4 + 1], reg[c * 4 + 1]);
+                const double e2 = __dmul_rn(A.evec[x * 4 + 2], reg[c * 4 + 2]);
+                const double e3 = __dmul_rn(A.evec[x * 4 + 3], reg[c * 4 + 3]);
+                const double *tp = s_tip + row * 4;
+                v = __dadd_rn(__dadd_rn(__dmul_rn(e0, tp[0]), __dmul_rn(e1, tp[1])),
+                              __dadd_rn(__dmul_rn(e2, tp[2]), __dmul_rn(e3, tp[3])));
+            }
+            reg[B + q] = v;
+        }
+        __syncthreads();
+        if (!active) { k += kn; continue; }
+
+        for (int kk = 0; kk < kn; kk++, k++) {
+            const CONST_AS DevOp *op = ops + k;
+            const bool leafL = op->left_kind == CHILD_LEAF;
+            const bool leafR = op->right_kind == CHILD_LEAF;
+            int sc = 0;
+            const int sL = nsL, sR = nsR;
+            if (!leafL) sc += pf_sc;
+            if (HAS_LOAD && op->right_kind == CHILD_LOAD) {
+                // both children come from memory: the left one was streamed into PF; the right
+                // one is read now into `prev`, which is dead here (it is not an input of this op)
+                load_vec4_off<C>(op->ld, voff, prev);
+                prev_sc = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(op->ld_sc) + soff);
+            }
+            if (!leafR) sc += prev_sc;
+            // ---- request op k+1's memory inputs while this op computes (sentinel at nops);
+            //      the vector itself is streamed inside node_update4, slice by slice
+            // Requests that op k+1 does not need keep the SAME instruction sequence (so the
+            // compiler can count vmcnt and op k's stores stay in flight) but are folded onto one
+            // small cache-resident window of the dummy buffers: no memory traffic.
+            const CONST_AS DevOp *nx = ops + (k + 1);
+            const int nreal = nx->real_mask;
+            const char *nx_pf = reinterpret_cast<const char *>(nx->pf) + ((nreal & 1) ? voff : (uint32_t)(lane * 16));
+            pf_sc = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(nx->pf_sc) +
+                                                       ((nreal & 1) ? soff : (uint32_t)(lane * 2)));
+            nsL = *(nx->sl + ((nreal & 2) ? poff : (uint32_t)lane));
+            nsR = *(nx->sr + ((nreal & 4) ? poff : (uint32_t)lane));
+            const double lh_max = node_update4<C>(leafL, leafR, s_reg + op->lds_left, s_reg + op->lds_right,
+                                                  s_tip, U, uinv, sL, sR, A.state_unknown, nx_pf, PF, prev);
+            // ---- scaling (SIMD rule, phylokernel.h:379-392,461-474); TIP-TIP never scales
+            const bool do_scale = !(leafL && leafR) && (lh_max < kScalingThreshold) && (invar == 0.0);
+            double my_scale = 0.0;
+            if (do_scale) {
+#pragma unroll
+                for (int e = 0; e < B; e++) prev[e] *= kScalingThresholdInv;
+                sc += 1;
+                my_scale = (ptn < A.nptn) ? kLogScalingThreshold * freq : 0.0;
+            }
+            prev_sc = sc;
+#ifndef IQHIP_ABLATE_NOSTORE  // timing-only build switch; never defined in the shipped library
+            store_vec4_off<C>(op->dst, voff, prev);
+            *reinterpret_cast<int16_t *>(reinterpret_cast<char *>(op->dst_sc) + soff) = (int16_t)sc;
+#endif
+            // deterministic reduction: wave partial -> slab[2+k][gw]
+            const unsigned long long any = __ballot(do_scale);
+            double ws = 0.0;
+            if (any) ws = wave_sum(my_scale);
+            if (lane == 0) A.slab[(size_t)(2 + k) * A.nwaves + gw] = ws;
+        }
+    }
+    if (A.nops == 0) __syncthreads();  // s_tip / s_val visibility for a root-only launch
+    if (!active) return;
 
     if (A.has_root) {
         // ---- branch lnL, phylokernel.h:806-838 (leaf form) / :930-956 (internal form)
@@ -238,7 +394,7 @@ __global__ __launch_bounds__(256) void k_traverse4(const Trav4Args A) {
 #pragma unroll
             for (int e = 0; e < B; e++) Bv[e] = prev[e];
         } else {
-            load_vec4<C>(A.root.b, tile, lane, Bv);
+            load_vec4<C>(A.root.b, tl, lane, Bv);
         }
         double lh = 0.0;
         if (A.root.a_kind == CHILD_LEAF) {
@@ -251,7 +407,7 @@ __global__ __launch_bounds__(256) void k_traverse4(const Trav4Args A) {
 #pragma unroll
                 for (int e = 0; e < B; e++) Av[e] = prev[e];
             } else {
-                load_vec4<C>(A.root.a, tile, lane, Av);
+                load_vec4<C>(A.root.a, tl, lane, Av);
             }
 #pragma unroll
             for (int e = 0; e < B; e++) lh = fma(s_val[e] * Av[e], Bv[e], lh);
@@ -268,17 +424,40 @@ __global__ __launch_bounds__(256) void k_traverse4(const Trav4Args A) {
     }
 }
 
-template <int C>
-static hipError_t launch_trav_c(iqhip_engine *e, const Trav4Args &A) {
-    const int grid = (int)((e->ntiles + 3) / 4);
-    hipLaunchKernelGGL(k_traverse4<C>, dim3(grid), dim3(256), 0, e->stream, A);
+template <int C, int WG, bool HAS_LOAD>
+static hipError_t launch_trav_l(iqhip_engine *e, Trav4Args &A) {
+    constexpr int B = 4 * C;
+    const size_t lds = (size_t)(128 + B + (size_t)e->plan_lds_doubles) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse4<C, WG, HAS_LOAD>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    constexpr int WPB = WG / 64;
+    const int grid = (int)((e->ntiles + WPB - 1) / WPB);
+    hipLaunchKernelGGL((k_traverse4<C, WG, HAS_LOAD>), dim3(grid), dim3(WG), lds, e->stream, A);
     return hipGetLastError();
+}
+
+template <int C, int WG>
+static hipError_t launch_trav_c(iqhip_engine *e, Trav4Args &A) {
+    return e->plan_has_load ? launch_trav_l<C, WG, true>(e, A) : launch_trav_l<C, WG, false>(e, A);
+}
+
+template <int C>
+static hipError_t launch_trav_wg(iqhip_engine *e, Trav4Args &A) {
+    switch (e->wg_size) {
+        case 64: return launch_trav_c<C, 64>(e, A);
+        case 128: return launch_trav_c<C, 128>(e, A);
+        default: return launch_trav_c<C, 256>(e, A);
+    }
 }
 
 hipError_t launch_traverse4(iqhip_engine *e, int nops, const DevBranch *root, int nwaves) {
     Trav4Args A;
     A.ops = e->d_ops;
-    A.opmat = e->d_opmat;
+    A.evec = e->d_evec;
     A.inv_evec = e->d_inv_evec;
     A.tip = e->d_tip;
     A.freq = e->d_freq;
@@ -296,13 +475,13 @@ hipError_t launch_traverse4(iqhip_engine *e, int nops, const DevBranch *root, in
     A.has_root = root ? 1 : 0;
     if (root) A.root = *root; else A.root = DevBranch{nullptr, nullptr, nullptr, 0, 0, 0.0};
     switch (e->ncat) {
-        case 1: return launch_trav_c<1>(e, A);
-        case 2: return launch_trav_c<2>(e, A);
-        case 3: return launch_trav_c<3>(e, A);
-        case 4: return launch_trav_c<4>(e, A);
-        case 5: return launch_trav_c<5>(e, A);
-        case 6: return launch_trav_c<6>(e, A);
-        case 8: return launch_trav_c<8>(e, A);
+        case 1: return launch_trav_wg<1>(e, A);
+        case 2: return launch_trav_wg<2>(e, A);
+        case 3: return launch_trav_wg<3>(e, A);
+        case 4: return launch_trav_wg<4>(e, A);
+        case 5: return launch_trav_wg<5>(e, A);
+        case 6: return launch_trav_wg<6>(e, A);
+        case 8: return launch_trav_wg<8>(e, A);
         default: return hipErrorInvalidValue;
     }
 }

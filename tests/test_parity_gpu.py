@@ -289,3 +289,24 @@ def test_async_result_buffer_path(pkg, synth, oracle):
     total = out[0] + out[2:2 + len(plan)].sum()
     assert abs(total - ref) <= LNL_RTOL * abs(ref)
     assert lib.iqhip_bind_result_buffer(eng, None, 0) == 0
+
+
+def test_lds_chunking_of_long_plans(pkg, synth, oracle, monkeypatch):
+    """plans whose per-branch LDS regions exceed the budget are cut into chunks (barrier + refill)."""
+    monkeypatch.setenv("IQHIP_LDS_KB", "8")
+    t, ot, *_ = make_case(synth, oracle, pkg, 40, 500, 4, 4, 91, missing=0.05)
+    monkeypatch.delenv("IQHIP_LDS_KB")
+    lnl = t.compute_likelihood()
+    ref, _ = ot.likelihood()
+    assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+    assert check_all_vectors(t, ot) == 40 - 2
+
+
+@pytest.mark.parametrize("wg", ["64", "128"])
+def test_other_workgroup_sizes(pkg, synth, oracle, monkeypatch, wg):
+    monkeypatch.setenv("IQHIP_WG", wg)
+    t, ot, *_ = make_case(synth, oracle, pkg, 13, 777, 4, 4, 93, missing=0.05)
+    monkeypatch.delenv("IQHIP_WG")
+    lnl = t.compute_likelihood()
+    ref, _ = ot.likelihood()
+    assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
