@@ -305,8 +305,6 @@ extern "C" int iqhip_set_model(iqhip_engine *e, const double *eval, const double
 // plan building
 // ---------------------------------------------------------------------------------------
 static int ensure_plan_capacity(iqhip_engine *e, int nops) {
-    if (nops > e->result_cap - 1)
-        return fail(IQHIP_ERR_INVALID, "too many node updates in one submission");
     if (nops <= e->ops_cap) return IQHIP_OK;
     HIPCHK(hipStreamSynchronize(e->stream));
     int cap = std::max(64, nops * 2);
@@ -361,7 +359,9 @@ static int resolve_child(iqhip_engine *e, uint64_t key, int32_t leaf, int prev_d
 }
 
 static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *last_dst) {
-    int rc = ensure_plan_capacity(e, nops + 1);  // + sentinel
+    constexpr int kSentinels = 4;  // >= the kernel's deepest look-ahead (leaf states: 4 ops)
+    if (nops + 2 > e->result_cap) return fail(IQHIP_ERR_INVALID, "too many node updates in one submission");
+    int rc = ensure_plan_capacity(e, nops + kSentinels);
     if (rc) return rc;
     if (e->staging_busy) {  // the previous submission may still be copying h_ops
         HIPCHK(hipEventSynchronize(e->staging_free));
@@ -425,7 +425,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         d.right_len = rlen;
         prev_dst = didx;
     }
-    dummy_op(e->h_ops[nops]);  // sentinel: target of the last op's unconditional prefetch
+    for (int q = 0; q < kSentinels; q++) dummy_op(e->h_ops[nops + q]);  // targets of the look-ahead requests
     *last_dst = prev_dst;
     // LDS layout of the per-(op, child) regions, cut into chunks that fit the budget
     {
@@ -447,7 +447,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         if (nops > 0) e->h_ops[chunk_start].chunk_nops = nops - chunk_start;
         e->plan_lds_doubles = max_used;
     }
-    HIPCHK(hipMemcpyAsync(e->d_ops, e->h_ops, sizeof(DevOp) * (nops + 1), hipMemcpyHostToDevice,
+    HIPCHK(hipMemcpyAsync(e->d_ops, e->h_ops, sizeof(DevOp) * (nops + kSentinels), hipMemcpyHostToDevice,
                           e->stream));
     HIPCHK(hipEventRecord(e->staging_free, e->stream));
     e->staging_busy = true;

@@ -162,7 +162,7 @@ __device__ __forceinline__ double node_update4(bool leafL, bool leafR, const dou
                                                const double *regR, const double *s_tip,
                                                const CONST_AS double *U, const CONST_AS double *uinv,
                                                int sL, int sR, int state_unknown, const char *nx_pf,
-                                               double (&PF)[4 * C], double (&prev)[4 * C]) {
+                                               char *dst, double (&PF)[4 * C], double (&prev)[4 * C]) {
     bool slowL = false, slowR = false;
     int rowL = 0, rowR = 0;
     if (leafL) {
@@ -222,6 +222,13 @@ __device__ __forceinline__ double node_update4(bool leafL, bool leafR, const dou
             prev[c * 4 + i] = o;
             lh_max = fmax(lh_max, fabs(o));
         }
+        // store the slice now (unscaled; the rare rescale re-stores the vector): every wave runs
+        // the same op at about the same time, so stores issued only at the end of the op reach the
+        // memory system in chip-wide bursts that alternate with compute instead of overlapping it
+#ifndef IQHIP_ABLATE_NOSTORE  // timing-only build switch; never defined in the shipped library
+        *reinterpret_cast<double2 *>(dst + (2 * c) * 1024) = make_double2(prev[c * 4], prev[c * 4 + 1]);
+        *reinterpret_cast<double2 *>(dst + (2 * c + 1) * 1024) = make_double2(prev[c * 4 + 2], prev[c * 4 + 3]);
+#endif
     }
     return (leafL && leafR) ? 0.0 : lh_max;
 }
@@ -285,7 +292,12 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
     const CONST_AS DevOp *ops = as_const(A.ops);
 
     double prev[B], PF[B];
-    int pf_sc = 0, prev_sc = 0, nsL = 0, nsR = 0;
+    // leaf state bytes are read once per traversal (cold HBM misses) and are pure inputs, so they
+    // are requested SD ops ahead and carried in a small register queue
+    constexpr int SD = 4;
+    int pf_sc = 0, prev_sc = 0, qL[SD], qR[SD];
+#pragma unroll
+    for (int q = 0; q < SD; q++) { qL[q] = 0; qR[q] = 0; }
 #pragma unroll
     for (int e = 0; e < B; e++) { prev[e] = 0.0; PF[e] = 0.0; }
 
@@ -297,8 +309,12 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
         load_vec4_off<C>(nx->pf, (nreal & 1) ? voff : (uint32_t)(lane * 16), PF);
         pf_sc = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(nx->pf_sc) +
                                                    ((nreal & 1) ? soff : (uint32_t)(lane * 2)));
-        nsL = *(nx->sl + ((nreal & 2) ? poff : (uint32_t)lane));
-        nsR = *(nx->sr + ((nreal & 4) ? poff : (uint32_t)lane));
+#pragma unroll
+        for (int q = 0; q < SD; q++) {  // ops[nops .. nops+SD) are sentinels
+            const int qreal = ops[q].real_mask;
+            qL[q] = *(ops[q].sl + ((qreal & 2) ? poff : (uint32_t)lane));
+            qR[q] = *(ops[q].sr + ((qreal & 4) ? poff : (uint32_t)lane));
+        }
     }
 
     int k = 0;
@@ -340,7 +356,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
             const bool leafL = op->left_kind == CHILD_LEAF;
             const bool leafR = op->right_kind == CHILD_LEAF;
             int sc = 0;
-            const int sL = nsL, sR = nsR;
+            const int sL = qL[0], sR = qR[0];
             if (!leafL) sc += pf_sc;
             if (HAS_LOAD && op->right_kind == CHILD_LOAD) {
                 // both children come from memory: the left one was streamed into PF; the right
@@ -359,26 +375,37 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
             const char *nx_pf = reinterpret_cast<const char *>(nx->pf) + ((nreal & 1) ? voff : (uint32_t)(lane * 16));
             pf_sc = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(nx->pf_sc) +
                                                        ((nreal & 1) ? soff : (uint32_t)(lane * 2)));
-            nsL = *(nx->sl + ((nreal & 2) ? poff : (uint32_t)lane));
-            nsR = *(nx->sr + ((nreal & 4) ? poff : (uint32_t)lane));
+#pragma unroll
+            for (int q = 0; q + 1 < SD; q++) { qL[q] = qL[q + 1]; qR[q] = qR[q + 1]; }
+            {
+                const CONST_AS DevOp *fx = ops + (k + SD);
+                const int freal = fx->real_mask;
+                qL[SD - 1] = *(fx->sl + ((freal & 2) ? poff : (uint32_t)lane));
+                qR[SD - 1] = *(fx->sr + ((freal & 4) ? poff : (uint32_t)lane));
+            }
+            char *dstp = reinterpret_cast<char *>(op->dst) + voff;
             const double lh_max = node_update4<C>(leafL, leafR, s_reg + op->lds_left, s_reg + op->lds_right,
-                                                  s_tip, U, uinv, sL, sR, A.state_unknown, nx_pf, PF, prev);
+                                                  s_tip, U, uinv, sL, sR, A.state_unknown, nx_pf, dstp, PF, prev);
             // ---- scaling (SIMD rule, phylokernel.h:379-392,461-474); TIP-TIP never scales
             const bool do_scale = !(leafL && leafR) && (lh_max < kScalingThreshold) && (invar == 0.0);
             double my_scale = 0.0;
-            if (do_scale) {
+            const unsigned long long any = __ballot(do_scale);
+            if (__builtin_expect(any != 0, 0)) {  // rare, wave-uniform
+                if (do_scale) {
 #pragma unroll
-                for (int e = 0; e < B; e++) prev[e] *= kScalingThresholdInv;
-                sc += 1;
-                my_scale = (ptn < A.nptn) ? kLogScalingThreshold * freq : 0.0;
+                    for (int e = 0; e < B; e++) prev[e] *= kScalingThresholdInv;
+                    sc += 1;
+                    my_scale = (ptn < A.nptn) ? kLogScalingThreshold * freq : 0.0;
+#ifndef IQHIP_ABLATE_NOSTORE
+                    store_vec4_off<C>(op->dst, voff, prev);
+#endif
+                }
             }
             prev_sc = sc;
-#ifndef IQHIP_ABLATE_NOSTORE  // timing-only build switch; never defined in the shipped library
-            store_vec4_off<C>(op->dst, voff, prev);
+#ifndef IQHIP_ABLATE_NOSTORE
             *reinterpret_cast<int16_t *>(reinterpret_cast<char *>(op->dst_sc) + soff) = (int16_t)sc;
 #endif
             // deterministic reduction: wave partial -> slab[2+k][gw]
-            const unsigned long long any = __ballot(do_scale);
             double ws = 0.0;
             if (any) ws = wave_sum(my_scale);
             if (lane == 0) A.slab[(size_t)(2 + k) * A.nwaves + gw] = ws;

@@ -1,0 +1,89 @@
+// store_probe.hip -- microbenchmark (not part of the product): what does the traversal kernel's
+// memory pattern cost by itself?  1563 waves x 48 steps; per step each wave optionally does
+// NFMA dependent-free fp64 FMAs per lane, optionally loads 8 KiB, and stores 8 KiB to slab[step].
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <int NFMA, bool LOAD, bool STORE, bool SPREAD>
+__global__ __launch_bounds__(256, 2) void probe(double *const *slabs, int nsteps, long ntiles, double *out) {
+    const int lane = threadIdx.x & 63;
+    const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const size_t off = (size_t)tile * 1024 + lane * 2;  // doubles: tile*64*16 + lane*2
+    double v[16];
+    for (int e = 0; e < 16; e++) v[e] = 1.0 + lane * 1e-3 + e;
+    for (int k = 0; k < nsteps; k++) {
+        double *dst = slabs[k] + off;
+        if (LOAD && k >= 2) {
+            const double *src = slabs[k - 2] + off;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                double2 t = *reinterpret_cast<const double2 *>(src + j * 128);
+                v[2 * j] += t.x; v[2 * j + 1] += t.y;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+#pragma unroll
+            for (int r = 0; r < NFMA / 16; r++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[c * 4 + e] = fma(v[c * 4 + e], 1.0000001, 1e-9);
+            if (STORE && SPREAD) {
+                *reinterpret_cast<double2 *>(dst + (2 * c) * 128) = make_double2(v[c * 4], v[c * 4 + 1]);
+                *reinterpret_cast<double2 *>(dst + (2 * c + 1) * 128) = make_double2(v[c * 4 + 2], v[c * 4 + 3]);
+            }
+        }
+        if (STORE && !SPREAD) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) *reinterpret_cast<double2 *>(dst + j * 128) = make_double2(v[2 * j], v[2 * j + 1]);
+        }
+    }
+    double s = 0;
+    for (int e = 0; e < 16; e++) s += v[e];
+    if (s == 12345.678) out[0] = s;
+}
+
+template <int NFMA, bool LOAD, bool STORE, bool SPREAD>
+float run(double *const *d_slabs, int nsteps, long ntiles, double *d_out, const char *name) {
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    const int grid = (int)((ntiles + 3) / 4);
+    for (int w = 0; w < 3; w++) hipLaunchKernelGGL((probe<NFMA, LOAD, STORE, SPREAD>), dim3(grid), dim3(256), 0, 0, d_slabs, nsteps, ntiles, d_out);
+    CHECK(hipEventRecord(a));
+    const int reps = 20;
+    for (int w = 0; w < reps; w++) hipLaunchKernelGGL((probe<NFMA, LOAD, STORE, SPREAD>), dim3(grid), dim3(256), 0, 0, d_slabs, nsteps, ntiles, d_out);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+    ms /= reps;
+    printf("%-44s %8.4f ms\n", name, ms);
+    return ms;
+}
+
+int main(int argc, char **argv) {
+    const long nptn = argc > 1 ? atol(argv[1]) : 100000;
+    const int nsteps = 48;
+    const long ntiles = (nptn + 63) / 64;
+    std::vector<double *> slabs(nsteps);
+    for (int k = 0; k < nsteps; k++) { CHECK(hipMalloc(&slabs[k], ntiles * 1024 * sizeof(double))); CHECK(hipMemset(slabs[k], 0, ntiles * 1024 * sizeof(double))); }
+    double **d_slabs; CHECK(hipMalloc(&d_slabs, nsteps * sizeof(double *)));
+    CHECK(hipMemcpy(d_slabs, slabs.data(), nsteps * sizeof(double *), hipMemcpyHostToDevice));
+    double *d_out; CHECK(hipMalloc(&d_out, 8));
+    const double mb = nsteps * ntiles * 8192.0 / 1e6;
+    printf("patterns %ld, waves %ld, bytes stored per launch %.1f MB\n", nptn, ntiles, mb);
+    float t;
+    t = run<0, false, true, false>(d_slabs, nsteps, ntiles, d_out, "stores only (end of step)"); printf("   -> %.2f TB/s\n", mb / t / 1e3);
+    run<0, false, true, true>(d_slabs, nsteps, ntiles, d_out, "stores only (spread)");
+    run<256, false, false, false>(d_slabs, nsteps, ntiles, d_out, "256 FMA/lane/step only");
+    run<512, false, false, false>(d_slabs, nsteps, ntiles, d_out, "512 FMA/lane/step only");
+    run<256, false, true, false>(d_slabs, nsteps, ntiles, d_out, "256 FMA + stores at end");
+    run<256, false, true, true>(d_slabs, nsteps, ntiles, d_out, "256 FMA + stores spread");
+    run<512, false, true, false>(d_slabs, nsteps, ntiles, d_out, "512 FMA + stores at end");
+    run<512, false, true, true>(d_slabs, nsteps, ntiles, d_out, "512 FMA + stores spread");
+    run<256, true, true, true>(d_slabs, nsteps, ntiles, d_out, "256 FMA + loads(k-2) + stores spread");
+    run<512, true, true, true>(d_slabs, nsteps, ntiles, d_out, "512 FMA + loads(k-2) + stores spread");
+    return 0;
+}
