@@ -44,11 +44,14 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     *out = nullptr;
     if (nptn <= 0 || ntaxa < 2 || ncat < 1)
         return fail(IQHIP_ERR_INVALID, "iqhip_create: bad nptn/ntaxa/ncat");
-    if (nstates != 4)
+    if (nstates != 4 && nstates != 20 && nstates != 64)
         return fail(IQHIP_ERR_UNSUPPORTED,
-                    "iqhip_create: nstates must be 4 in this build (20/64 MFMA path pending)");
-    if (!(ncat >= 1 && ncat <= 8 && ncat != 7))
-        return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_create: ncat must be in {1..6,8}");
+                    "iqhip_create: nstates must be 4, 20 or 64 (the reference's SIMD dispatch cases; "
+                    "other counts use its scalar kernel)");
+    if (nstates == 4 && !(ncat >= 1 && ncat <= 8 && ncat != 7))
+        return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_create: 4-state path supports ncat in {1..6,8}");
+    if (nstates != 4 && ncat > 16)
+        return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_create: ncat must be <= 16");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(IQHIP_ERR_NO_DEVICE, "iqhip_create: no HIP device available");
@@ -61,9 +64,10 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     e->ncat = ncat;
     e->ntaxa = ntaxa;
     e->nptn = nptn;
-    e->tile = 64;
+    e->mfma = nstates != 4;
+    e->tile = e->mfma ? 16 : 64;
     e->block = nstates * ncat;
-    e->nptn_pad = round_up(nptn, e->tile);
+    e->nptn_pad = round_up(nptn, 64);
     e->ntiles = e->nptn_pad / e->tile;
 
     hipError_t s = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -125,7 +129,7 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
         if (s.sc) hipFree(s.sc);
     }
     void *ptrs[] = {e->d_states, e->d_freq, e->d_invar, e->d_eval, e->d_evec, e->d_inv_evec,
-                    e->d_rates, e->d_props, e->d_tip, e->d_ops, e->d_opmat, e->d_val, e->d_slab,
+                    e->d_rates, e->d_props, e->d_tip, e->d_ops, e->d_val, e->d_slab,
                     e->d_theta, e->d_pattern_lh, e->d_result_own, e->dummy.plh, e->dummy.sc};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -281,7 +285,7 @@ extern "C" int iqhip_set_model(iqhip_engine *e, const double *eval, const double
                                int state_unknown, const double *tip_partial_lh) {
     if (!e || !eval || !evec || !inv_evec || !rates || !props || !tip_partial_lh)
         return fail(IQHIP_ERR_INVALID, "null argument");
-    if (state_unknown < e->n || state_unknown > 31)
+    if (state_unknown < e->n || state_unknown > (e->mfma ? 255 : 31))
         return fail(IQHIP_ERR_INVALID, "iqhip_set_model: state_unknown out of range");
     if (e->aln_set && state_unknown != e->state_unknown)
         return fail(IQHIP_ERR_INVALID, "iqhip_set_model: state_unknown changed after set_alignment");
@@ -399,26 +403,32 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
             return fail(IQHIP_ERR_INVALID, "node update writes onto one of its own children");
         if (lkind == CHILD_PREV && rkind == CHILD_PREV)
             return fail(IQHIP_ERR_INVALID, "node update uses the same vector for both children");
-        // canonical form (the Hadamard product commutes): left in {LEAF, PF}, right in
-        // {LEAF, PREV}; the only other shape is (PF, LOAD): two memory children, neither of
-        // them the previous result -- the kernel reads the second one synchronously.
         double llen = o.left_len, rlen = o.right_len;
-        auto swap_children = [&]() {
-            std::swap(lp, rp); std::swap(lsc, rsc); std::swap(lst, rst);
-            std::swap(lkind, rkind); std::swap(llen, rlen);
-        };
-        if (lkind == CHILD_PREV) swap_children();                              // PREV goes right
-        else if (lkind == CHILD_LEAF && rkind == CHILD_LOAD) swap_children();  // memory child goes left
-        if (lkind == CHILD_LOAD) lkind = CHILD_PF;
-        if (rkind == CHILD_LOAD) e->plan_has_load = true;                      // (PF, LOAD)
         d.dst = e->slabs[didx].plh;
         d.dst_sc = e->slabs[didx].sc;
-        if (lkind == CHILD_PF) { d.pf = lp; d.pf_sc = lsc; d.real_mask |= 1; }
-        if (rkind == CHILD_LOAD) { d.ld = rp; d.ld_sc = rsc; }
-        if (lkind == CHILD_LEAF) { d.sl = lst; d.real_mask |= 2; }
-        if (rkind == CHILD_LEAF) { d.sr = rst; d.real_mask |= 4; }
-        if (e->ablate & 1) d.real_mask &= ~1;  // timing-only: never stream a child (results wrong)
-        if (e->ablate & 2) d.real_mask &= ~6;  // timing-only: never read leaf states
+        if (e->mfma) {
+            // matrix-core path: both children are read from memory (pf = left, ld = right)
+            if (lkind != CHILD_LEAF) { lkind = CHILD_LOAD; d.pf = lp; d.pf_sc = lsc; } else d.sl = lst;
+            if (rkind != CHILD_LEAF) { rkind = CHILD_LOAD; d.ld = rp; d.ld_sc = rsc; } else d.sr = rst;
+        } else {
+            // canonical form (the Hadamard product commutes): left in {LEAF, PF}, right in
+            // {LEAF, PREV}; the only other shape is (PF, LOAD): two memory children, neither of
+            // them the previous result -- the kernel reads the second one synchronously.
+            auto swap_children = [&]() {
+                std::swap(lp, rp); std::swap(lsc, rsc); std::swap(lst, rst);
+                std::swap(lkind, rkind); std::swap(llen, rlen);
+            };
+            if (lkind == CHILD_PREV) swap_children();                              // PREV goes right
+            else if (lkind == CHILD_LEAF && rkind == CHILD_LOAD) swap_children();  // memory child goes left
+            if (lkind == CHILD_LOAD) lkind = CHILD_PF;
+            if (rkind == CHILD_LOAD) e->plan_has_load = true;                      // (PF, LOAD)
+            if (lkind == CHILD_PF) { d.pf = lp; d.pf_sc = lsc; d.real_mask |= 1; }
+            if (rkind == CHILD_LOAD) { d.ld = rp; d.ld_sc = rsc; }
+            if (lkind == CHILD_LEAF) { d.sl = lst; d.real_mask |= 2; }
+            if (rkind == CHILD_LEAF) { d.sr = rst; d.real_mask |= 4; }
+            if (e->ablate & 1) d.real_mask &= ~1;  // timing-only: never stream a child (results wrong)
+            if (e->ablate & 2) d.real_mask &= ~6;  // timing-only: never read leaf states
+        }
         d.left_kind = lkind;
         d.right_kind = rkind;
         d.left_len = llen;
@@ -429,18 +439,28 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
     *last_dst = prev_dst;
     // LDS layout of the per-(op, child) regions, cut into chunks that fit the budget
     {
-        const int budget = (e->lds_budget_bytes / 8) - 128 - B;
+        int budget;
+        if (e->mfma) {
+            const int MT = (e->n + 15) / 16, KS = e->n / 4;
+            const int fixed = 2 * MT * KS * 64 + (e->state_unknown + 1 - e->n) * e->n;
+            budget = (150 * 1024) / 8 - fixed;
+        } else {
+            budget = (e->lds_budget_bytes / 8) - 128 - B;
+        }
         int chunk_start = 0, used = 0, max_used = 0;
         for (int k = 0; k < nops; k++) {
             DevOp &d = e->h_ops[k];
-            const int need = (d.left_kind == CHILD_LEAF ? 6 * B : B) + (d.right_kind == CHILD_LEAF ? 6 * B : B);
+            const int szl = (!e->mfma && d.left_kind == CHILD_LEAF) ? 6 * B : B;
+            const int szr = (!e->mfma && d.right_kind == CHILD_LEAF) ? 6 * B : B;
+            const int need = szl + szr;
+            if (need > budget) return fail(IQHIP_ERR_UNSUPPORTED, "nstates*ncat too large for the LDS plan regions");
             if (used + need > budget && k > chunk_start) {
                 e->h_ops[chunk_start].chunk_nops = k - chunk_start;
                 chunk_start = k;
                 used = 0;
             }
             d.lds_left = used;
-            d.lds_right = used + (d.left_kind == CHILD_LEAF ? 6 * B : B);
+            d.lds_right = used + szl;
             used += need;
             if (used > max_used) max_used = used;
         }
@@ -504,8 +524,10 @@ static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, 
     if (rc) return rc;
     const int nwaves = (int)e->ntiles;
     timing_begin(e);
-    HIPCHK(launch_traverse4(e, nops, has_root ? &br : nullptr, nwaves));
+    if (e->mfma) HIPCHK(launch_traverse_mfma(e, nops, nwaves));
+    else HIPCHK(launch_traverse4(e, nops, has_root ? &br : nullptr, nwaves));
     timing_end(e);
+    if (e->mfma && has_root) HIPCHK(launch_stream_mfma(e, 0, &br, br.len, nwaves));
     if (has_root) HIPCHK(launch_reduce(e, 0, 2 + nops, nwaves));
     else HIPCHK(launch_reduce(e, 2, nops, nwaves));
     e->last_nops = nops;
@@ -581,7 +603,8 @@ extern "C" int iqhip_compute_theta(iqhip_engine *e, iqhip_branch_end a, iqhip_br
     DevBranch br;
     rc = build_branch(e, a, b, 0.0, -1, &br);
     if (rc) return rc;
-    HIPCHK(launch_theta4(e, br));
+    if (e->mfma) HIPCHK(launch_stream_mfma(e, 1, &br, 0.0, (int)e->ntiles));
+    else HIPCHK(launch_theta4(e, br));
     e->theta_valid = true;
     return IQHIP_OK;
 }
@@ -594,7 +617,8 @@ extern "C" int iqhip_derv_async(iqhip_engine *e, double len) {
     rc = ensure_slab_rows(e, 2);
     if (rc) return rc;
     const int nwaves = (int)e->ntiles;
-    HIPCHK(launch_derv4(e, len, nwaves));
+    if (e->mfma) HIPCHK(launch_stream_mfma(e, 2, nullptr, len, nwaves));
+    else HIPCHK(launch_derv4(e, len, nwaves));
     HIPCHK(launch_reduce(e, 0, 2, nwaves));
     return IQHIP_OK;
 }
@@ -619,7 +643,8 @@ extern "C" int iqhip_lnl_from_theta(iqhip_engine *e, double len, double *lnl) {
     rc = ensure_slab_rows(e, 2);
     if (rc) return rc;
     const int nwaves = (int)e->ntiles;
-    HIPCHK(launch_lnl_theta4(e, len, nwaves));
+    if (e->mfma) HIPCHK(launch_stream_mfma(e, 3, nullptr, len, nwaves));
+    else HIPCHK(launch_lnl_theta4(e, len, nwaves));
     HIPCHK(launch_reduce(e, 0, 1, nwaves));
     rc = read_result(e, 1);
     if (rc) return rc;
@@ -673,8 +698,10 @@ extern "C" int iqhip_synchronize(iqhip_engine *e) {
 // ---------------------------------------------------------------------------------------
 // host views (layout conversion on the host; these are off the hot path)
 // ---------------------------------------------------------------------------------------
-static inline size_t dev_index4(int64_t p, int e_, int B) {
-    return (size_t)(p >> 6) * 64 * B + (size_t)(e_ >> 1) * 128 + (size_t)(p & 63) * 2 + (e_ & 1);
+static inline size_t dev_index(const iqhip_engine *e, int64_t p, int k) {
+    const int B = e->block;
+    if (e->mfma) return (size_t)(p >> 4) * 16 * B + (size_t)k * 16 + (size_t)(p & 15);
+    return (size_t)(p >> 6) * 64 * B + (size_t)(k >> 1) * 128 + (size_t)(p & 63) * 2 + (k & 1);
 }
 
 static int fetch_vec(iqhip_engine *e, const double *dptr, double *out) {
@@ -683,7 +710,7 @@ static int fetch_vec(iqhip_engine *e, const double *dptr, double *out) {
     HIPCHK(hipMemcpy(tmp.data(), dptr, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
     const int B = e->block;
     for (int64_t p = 0; p < e->nptn; p++)
-        for (int k = 0; k < B; k++) out[(size_t)p * B + k] = tmp[dev_index4(p, k, B)];
+        for (int k = 0; k < B; k++) out[(size_t)p * B + k] = tmp[dev_index(e, p, k)];
     return IQHIP_OK;
 }
 
@@ -731,7 +758,7 @@ extern "C" int iqhip_upload_partial(iqhip_engine *e, uint64_t key, const double 
     const int B = e->block;
     std::vector<double> tmp((size_t)e->nptn_pad * B, 0.0);
     for (int64_t p = 0; p < e->nptn; p++)
-        for (int k = 0; k < B; k++) tmp[dev_index4(p, k, B)] = partial_lh[(size_t)p * B + k];
+        for (int k = 0; k < B; k++) tmp[dev_index(e, p, k)] = partial_lh[(size_t)p * B + k];
     std::vector<int16_t> sc((size_t)e->nptn_pad, 0);
     memcpy(sc.data(), scale_num, sizeof(int16_t) * (size_t)e->nptn);
     HIPCHK(hipStreamSynchronize(e->stream));

@@ -72,6 +72,7 @@ struct iqhip_engine {
     int64_t nptn_pad = 0;  // padded to the tile size
     int64_t ntiles = 0;    // tiles of `tile` patterns
     int tile = 64;         // 64 (VALU path) or 16 (MFMA path)
+    bool mfma = false;     // nstates 20 / 64: matrix-core path (kernels_mfma.hip)
     int wg_size = 256;     // threads per workgroup of the traversal kernel (IQHIP_WG env)
     int ablate = 0;        // IQHIP_ABLATE: timing-only host-side switches (results wrong when set)
     int lds_budget_bytes = 64 * 1024;  // per-workgroup LDS for the per-branch regions (IQHIP_LDS_KB)
@@ -95,7 +96,6 @@ struct iqhip_engine {
     // per-call buffers
     iqhip::DevOp *d_ops = nullptr;
     int ops_cap = 0;
-    double *d_opmat = nullptr;  // [ops_cap][2][ncat][n][n]
     double *d_val = nullptr;    // 3*block doubles: val0,val1,val2 for branch kernels
     double *d_slab = nullptr;   // wave partials [nvals][nwaves]
     int64_t slab_cap = 0;
@@ -123,11 +123,15 @@ struct iqhip_engine {
 namespace iqhip {
 
 // kernels_valu4.hip
-hipError_t launch_echild(iqhip_engine *e, int nops);
 hipError_t launch_traverse4(iqhip_engine *e, int nops, const DevBranch *root, int nwaves);
 hipError_t launch_theta4(iqhip_engine *e, const DevBranch &br);
 hipError_t launch_derv4(iqhip_engine *e, double len, int nwaves);
 hipError_t launch_lnl_theta4(iqhip_engine *e, double len, int nwaves);
 hipError_t launch_reduce(iqhip_engine *e, int first_row, int nrows, int nwaves);
+
+// kernels_mfma.hip (nstates 20 / 64)
+hipError_t launch_traverse_mfma(iqhip_engine *e, int nops, int nwaves);
+// mode 0: branch lnL, 1: theta, 2: df/ddf from theta, 3: lnL from theta
+hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, double len, int nwaves);
 
 }  // namespace iqhip

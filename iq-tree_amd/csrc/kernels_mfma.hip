@@ -1,0 +1,371 @@
+// kernels_mfma.hip -- gfx950 kernels for the 20-state (protein) and 64-state (codon) paths.
+//
+// Here a node update is a genuine dense contraction per category (phylokernel.h:420-459):
+//     out[c] = U^-1 * ( (U*diag(exL[c]) * left[c]) .* (U*diag(exR[c]) * right[c]) )
+// with n x n matrices against n x (patterns) panels, so it runs on the fp64 matrix cores
+// (v_mfma_f64_16x16x4_f64).  Mapping:
+//   * a wave owns a tile of 16 patterns = the N dimension of the MFMA; the vectors live in HBM
+//     as [tile16][c][i][16 patterns], which is at once the B-operand image (k-step s of a
+//     child panel = 64 consecutive doubles, one coalesced 512-B load) and the D-result image
+//     (register r of M-tile m = rows 16m+4r..+3 = 64 consecutive doubles);
+//   * the A operands are only U and U^-1 (zero-padded to a multiple of 16 rows): the per-branch
+//     part of E = U*diag(ex) is folded into the B operand (one v_mul_f64 per k-step), so the
+//     matrices are staged into LDS once per launch, not once per branch;
+//   * the f64 accumulator layout (row = (lane>>4)+4r, col = lane&15) is exactly the B layout of
+//     the next product's k-step 4m+r, so the Hadamard product and the third contraction chain
+//     in registers with no lane movement and no LDS round trip;
+//   * leaves use tip_partial_lh columns as their B panel (read from the U^-1 image in LDS);
+//     the reference's "unknown state row is exactly 1.0" (phylokernel.h:228-232) is restored
+//     by a select on the accumulators.
+// Scaling follows the SIMD rule (phylokernel.h:461-474): per pattern max |out| over the whole
+// block; the vector is stored unscaled per category and re-scaled in place in the rare case.
+// This first version reads both children from memory (L2/MALL-resident after an earlier op of
+// the same launch); keeping the previous result in registers as in the DNA kernel is the next
+// optimisation step.
+#include "iqhip_internal.h"
+
+namespace iqhip {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double wave_sum_m(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct TravMArgs {
+    const DevOp *ops;
+    const double *evec;
+    const double *inv_evec;
+    const double *tip;      // [(state_unknown+1)][n]
+    const double *freq;
+    const double *invar;
+    const double *eval;
+    const double *rates;
+    double *slab;           // [nvals][nwaves]
+    int64_t ntiles;         // tiles of 16 patterns
+    int64_t nptn;
+    int nops;
+    int nwaves;
+    int ncat;
+    int state_unknown;
+};
+
+// LDS image index of A[m][s][lane]
+template <int KS>
+__device__ __forceinline__ int aidx(int m, int s, int lane) { return (m * KS + s) * 64 + lane; }
+
+template <int N, int WG>
+__global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
+    constexpr int MT = (N + 15) / 16;  // M tiles (rows padded to 16)
+    constexpr int KS = N / 4;          // k-steps of 4
+    constexpr int WPB = WG / 64;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *sU = smem;                       // [MT][KS][64]   A image of U     (rows x, k = i)
+    double *sUi = sU + MT * KS * 64;         // [MT][KS][64]   A image of U^-1  (rows i, k = x)
+    double *sTipx = sUi + MT * KS * 64;      // [nx][N]        tip vectors of states >= N
+    const int nx = A.state_unknown + 1 - N;
+    double *sReg = sTipx + nx * N;           // per (op, child) exponentials [C*N] of the chunk
+    const int C = A.ncat;
+    const int B = C * N;
+
+    for (int t = threadIdx.x; t < MT * KS * 64; t += WG) {
+        const int l = t & 63, ms = t >> 6, s = ms % KS, m = ms / KS;
+        const int row = 16 * m + (l & 15), k = 4 * s + (l >> 4);
+        sU[t] = row < N ? A.evec[row * N + k] : 0.0;
+        sUi[t] = row < N ? A.inv_evec[row * N + k] : 0.0;
+    }
+    for (int t = threadIdx.x; t < nx * N; t += WG) sTipx[t] = A.tip[N * N + t];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * WPB + wave;
+    const bool active = tile < A.ntiles;
+    const int64_t tl = active ? tile : 0;
+    const int p = lane & 15, g = lane >> 4;
+    const int64_t ptn = tl * 16 + p;
+    const size_t tbase = (size_t)tl * 16 * B;  // doubles
+    const double freq = A.freq[ptn];
+    const double invar = A.invar[ptn];
+
+    int k = 0;
+    while (k < A.nops) {
+        const int kn = A.ops[k].chunk_nops;
+        __syncthreads();
+        for (int t = threadIdx.x; t < kn * 2 * B; t += WG) {
+            const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B;
+            const DevOp &d = A.ops[k + o];
+            const double len = child ? d.right_len : d.left_len;
+            sReg[(child ? d.lds_right : d.lds_left) + e] = exp(A.eval[e % N] * (A.rates[e / N] * len));
+        }
+        __syncthreads();
+        if (!active) { k += kn; continue; }
+
+        for (int kk = 0; kk < kn; kk++, k++) {
+            const DevOp &op = A.ops[k];
+            const bool leafL = op.left_kind == CHILD_LEAF, leafR = op.right_kind == CHILD_LEAF;
+            const double *exL = sReg + op.lds_left, *exR = sReg + op.lds_right;
+            // the scale counter of a pattern is carried by its g == 0 lane only, so that every
+            // lane reads back from memory nothing but what it stored itself
+            int sc = 0, sL = 0, sR = 0;
+            if (leafL) sL = op.sl[ptn]; else if (g == 0) sc += op.pf_sc[ptn];
+            if (leafR) sR = op.sr[ptn]; else if (g == 0) sc += op.ld_sc[ptn];
+            const bool unkL = leafL && sL == A.state_unknown, unkR = leafR && sR == A.state_unknown;
+            const double *vL = op.pf + tbase, *vR = op.ld + tbase;
+            double *dst = op.dst + tbase;
+            double lmax = 0.0;
+            for (int c = 0; c < C; c++) {
+                v4f64 YL[MT], YR[MT];
+#pragma unroll
+                for (int m = 0; m < MT; m++) { YL[m] = (v4f64){0, 0, 0, 0}; YR[m] = (v4f64){0, 0, 0, 0}; }
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    const int i = 4 * s + g;  // this lane's k index
+                    double bl, br;
+                    if (leafL) {
+                        // tip_partial_lh[state][i] = U^-1[i][state] for state < N (phylotreesse.cpp:464-471)
+                        bl = sL < N ? sUi[aidx<KS>(i >> 4, sL >> 2, (sL & 3) * 16 + (i & 15))] : sTipx[(sL - N) * N + i];
+                    } else {
+                        bl = vL[(size_t)c * N * 16 + s * 64 + lane];
+                    }
+                    if (leafR) {
+                        br = sR < N ? sUi[aidx<KS>(i >> 4, sR >> 2, (sR & 3) * 16 + (i & 15))] : sTipx[(sR - N) * N + i];
+                    } else {
+                        br = vR[(size_t)c * N * 16 + s * 64 + lane];
+                    }
+                    bl *= exL[c * N + i];
+                    br *= exR[c * N + i];
+#pragma unroll
+                    for (int m = 0; m < MT; m++) {
+                        const double a = sU[aidx<KS>(m, s, lane)];
+                        YL[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl, YL[m], 0, 0, 0);
+                        YR[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, br, YR[m], 0, 0, 0);
+                    }
+                }
+                // T = YL .* YR; unknown-state leaf columns are exactly 1.0
+                v4f64 T[MT];
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const double a = unkL ? 1.0 : YL[m][r];
+                        const double b = unkR ? 1.0 : YR[m][r];
+                        T[m][r] = a * b;
+                    }
+                v4f64 O[MT];
+#pragma unroll
+                for (int m = 0; m < MT; m++) O[m] = (v4f64){0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    const double bt = T[s >> 2][s & 3];  // accumulator layout == B layout of k-step s
+#pragma unroll
+                    for (int m = 0; m < MT; m++)
+                        O[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(sUi[aidx<KS>(m, s, lane)], bt, O[m], 0, 0, 0);
+                }
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = 16 * m + 4 * r + g;
+                        if (16 * m + 4 * r < N) {  // whole 4-row group valid (N is a multiple of 4)
+                            dst[(size_t)(c * N + row) * 16 + p] = O[m][r];
+                            lmax = fmax(lmax, fabs(O[m][r]));
+                        }
+                    }
+            }
+            // column (pattern) max over the 4 lane groups
+            lmax = fmax(lmax, __shfl_xor(lmax, 16, 64));
+            lmax = fmax(lmax, __shfl_xor(lmax, 32, 64));
+            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0);
+            double my_scale = 0.0;
+            if (__any(do_scale)) {
+                if (do_scale) {
+                    for (int e = g; e < B; e += 4) dst[(size_t)e * 16 + p] *= kScalingThresholdInv;
+                    sc += 1;
+                    if (g == 0 && ptn < A.nptn) my_scale = kLogScalingThreshold * freq;
+                }
+            }
+            if (g == 0) op.dst_sc[ptn] = (int16_t)sc;
+            const double ws = wave_sum_m(my_scale);
+            if (lane == 0) A.slab[(size_t)(2 + k) * A.nwaves + (int)tl] = ws;
+        }
+    }
+}
+
+template <int N>
+static hipError_t launch_trav_m(iqhip_engine *e, TravMArgs &A) {
+    constexpr int MT = (N + 15) / 16, KS = N / 4, WG = 256;
+    const int nx = e->state_unknown + 1 - N;
+    const size_t lds = (size_t)(2 * MT * KS * 64 + nx * N + e->plan_lds_doubles) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma<N, WG>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int grid = (int)((A.ntiles + 3) / 4);
+    hipLaunchKernelGGL((k_traverse_mfma<N, WG>), dim3(grid), dim3(WG), lds, e->stream, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_traverse_mfma(iqhip_engine *e, int nops, int nwaves) {
+    TravMArgs A;
+    A.ops = e->d_ops;
+    A.evec = e->d_evec;
+    A.inv_evec = e->d_inv_evec;
+    A.tip = e->d_tip;
+    A.freq = e->d_freq;
+    A.invar = e->d_invar;
+    A.eval = e->d_eval;
+    A.rates = e->d_rates;
+    A.slab = e->d_slab;
+    A.ntiles = e->ntiles;
+    A.nptn = e->nptn;
+    A.nops = nops;
+    A.nwaves = nwaves;
+    A.ncat = e->ncat;
+    A.state_unknown = e->state_unknown;
+    if (nops <= 0) return hipSuccess;
+    switch (e->n) {
+        case 20: return launch_trav_m<20>(e, A);
+        case 64: return launch_trav_m<64>(e, A);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// streaming kernels on the [tile16][e][16] layout (generic n, ncat): lane = (pattern p, group g),
+// group g handles block entries e = g, g+4, ...; the 4 groups are combined with two shuffles.
+// MODE 0: branch lnL (phylokernel.h:806-838, :930-956)   -> slab[0], pattern_lh
+// MODE 1: theta = a .* b (phylokernel.h:535-573)
+// MODE 2: df/ddf from theta (phylokernel.h:583-651)      -> slab[0], slab[1]
+// MODE 3: lnL from theta (phylokernel.h:1067-1090)       -> slab[0], pattern_lh
+// ---------------------------------------------------------------------------------------
+struct StreamMArgs {
+    DevBranch br;
+    const double *tip;
+    const double *eval;
+    const double *rates;
+    const double *props;
+    const double *freq;
+    const double *invar;
+    double *theta;
+    double *pattern_lh;
+    double *slab;
+    int64_t ntiles;
+    int64_t nptn;
+    int nwaves;
+    int n;
+    int ncat;
+    double len;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_stream_mfma(const StreamMArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int N = A.n, B = A.n * A.ncat;
+    double *s_v0 = smem, *s_v1 = smem + B, *s_v2 = smem + 2 * B;
+    if (MODE != 1) {
+        for (int t = threadIdx.x; t < B; t += 256) {
+            const int c = t / N, i = t - c * N;
+            const double cof = A.eval[i] * A.rates[c];
+            const double v = exp(cof * A.len) * A.props[c];
+            s_v0[t] = v;
+            s_v1[t] = cof * v;
+            s_v2[t] = cof * (cof * v);
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= A.ntiles) return;
+    const int p = lane & 15, g = lane >> 4;
+    const int64_t ptn = tile * 16 + p;
+    const size_t tbase = (size_t)tile * 16 * B;
+    const bool in = ptn < A.nptn;
+    double lh = 0.0, d1 = 0.0, d2 = 0.0;
+    if (MODE == 0 || MODE == 1) {
+        const double *bv = A.br.b + tbase;
+        const bool leaf = A.br.a_kind == CHILD_LEAF;
+        const int s = leaf ? A.br.a_states[ptn] : 0;
+        const double *av = leaf ? A.tip + (size_t)s * N : A.br.a + tbase;
+        for (int e = g; e < B; e += 4) {
+            const double b = bv[(size_t)e * 16 + p];
+            const double a = leaf ? av[e % N] : av[(size_t)e * 16 + p];
+            if (MODE == 1) A.theta[tbase + (size_t)e * 16 + p] = a * b;
+            else lh = fma(s_v0[e] * a, b, lh);
+        }
+        if (MODE == 1) return;
+    } else {
+        const double *th = A.theta + tbase;
+        for (int e = g; e < B; e += 4) {
+            const double t = th[(size_t)e * 16 + p];
+            lh = fma(s_v0[e], t, lh);
+            if (MODE == 2) {
+                d1 = fma(s_v1[e], t, d1);
+                d2 = fma(s_v2[e], t, d2);
+            }
+        }
+    }
+    lh += __shfl_xor(lh, 16, 64);
+    lh += __shfl_xor(lh, 32, 64);
+    if (MODE == 2) {
+        d1 += __shfl_xor(d1, 16, 64);
+        d1 += __shfl_xor(d1, 32, 64);
+        d2 += __shfl_xor(d2, 16, 64);
+        d2 += __shfl_xor(d2, 32, 64);
+    }
+    lh += A.invar[ptn];
+    const double f = in ? A.freq[ptn] : 0.0;
+    const bool mine = (g == 0) && in;
+    if (MODE == 2) {
+        const double inv = 1.0 / fabs(lh);
+        const double dfp = d1 * inv;
+        const double ddfp = fma(-dfp, dfp, d2 * inv);
+        const double wa = wave_sum_m(mine ? dfp * f : 0.0), wb = wave_sum_m(mine ? ddfp * f : 0.0);
+        if (lane == 0) {
+            A.slab[tile] = wa;
+            A.slab[(size_t)A.nwaves + tile] = wb;
+        }
+    } else {
+        const double plh = log(fabs(lh));
+        if (g == 0) A.pattern_lh[ptn] = plh;
+        const double wa = wave_sum_m(mine ? plh * f : 0.0);
+        if (lane == 0) {
+            A.slab[tile] = wa;
+            A.slab[(size_t)A.nwaves + tile] = 0.0;
+        }
+    }
+}
+
+hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, double len, int nwaves) {
+    StreamMArgs A;
+    if (br) A.br = *br; else A.br = DevBranch{nullptr, nullptr, nullptr, 0, 0, 0.0};
+    A.tip = e->d_tip;
+    A.eval = e->d_eval;
+    A.rates = e->d_rates;
+    A.props = e->d_props;
+    A.freq = e->d_freq;
+    A.invar = e->d_invar;
+    A.theta = e->d_theta;
+    A.pattern_lh = e->d_pattern_lh;
+    A.slab = e->d_slab;
+    A.ntiles = e->ntiles;
+    A.nptn = e->nptn;
+    A.nwaves = nwaves;
+    A.n = e->n;
+    A.ncat = e->ncat;
+    A.len = len;
+    const int grid = (int)((e->ntiles + 3) / 4);
+    const size_t lds = (size_t)3 * e->block * sizeof(double);
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(k_stream_mfma<0>, dim3(grid), dim3(256), lds, e->stream, A); break;
+        case 1: hipLaunchKernelGGL(k_stream_mfma<1>, dim3(grid), dim3(256), lds, e->stream, A); break;
+        case 2: hipLaunchKernelGGL(k_stream_mfma<2>, dim3(grid), dim3(256), lds, e->stream, A); break;
+        default: hipLaunchKernelGGL(k_stream_mfma<3>, dim3(grid), dim3(256), lds, e->stream, A); break;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace iqhip

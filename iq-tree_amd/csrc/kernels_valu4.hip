@@ -35,32 +35,6 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ---------------------------------------------------------------------------------------
-// K1 (phylokernel.h:159-181): opmat[op][child][c][x][i] = U[x][i] * exp(eval[i]*rate_c*len)
-// one block per (op, child)
-// ---------------------------------------------------------------------------------------
-__global__ void k_echild(const DevOp *__restrict__ ops, int n, int ncat,
-                         const double *__restrict__ eval, const double *__restrict__ evec,
-                         const double *__restrict__ rates, double *__restrict__ opmat) {
-    const int op = blockIdx.x >> 1, child = blockIdx.x & 1;
-    const double len = child ? ops[op].right_len : ops[op].left_len;
-    const int nn = n * n, total = ncat * nn;
-    double *out = opmat + (size_t)blockIdx.x * total;
-    for (int t = threadIdx.x; t < total; t += blockDim.x) {
-        const int c = t / nn, xi = t - c * nn, i = xi % n;
-        out[t] = evec[xi] * exp(eval[i] * (rates[c] * len));
-    }
-}
-
-hipError_t launch_echild(iqhip_engine *e, int nops) {
-    if (nops <= 0) return hipSuccess;
-    int threads = e->n * e->n * e->ncat;
-    threads = threads < 64 ? 64 : (threads > 256 ? 256 : ((threads + 63) / 64) * 64);
-    hipLaunchKernelGGL(k_echild, dim3(nops * 2), dim3(threads), 0, e->stream, e->d_ops, e->n,
-                       e->ncat, e->d_eval, e->d_evec, e->d_rates, e->d_opmat);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------
 // child access for the 4-state path
 // ---------------------------------------------------------------------------------------
 template <int C>

@@ -528,6 +528,15 @@ double PhyloTree::computeLikelihoodBranchHIP(PhyloNeighbor *dad_branch, PhyloNod
     last_plan = plan;
     std::vector<double> sum_scale(plan.size(), 0.0);
     double lnl = 0.0;
+    if (dry_run && allreduce_hook) {
+        // CPU rehearsal of the sharded protocol (tests, gloo): the hook receives a HOST vector
+        // laid out like the device result {lnl, -, sum_scale[k]...}, fills in this rank's share
+        // and all-reduces it; no likelihood arithmetic happens in this library.
+        std::vector<double> res(2 + plan.size(), 0.0);
+        allreduce_hook(res.data(), (int)res.size(), allreduce_ctx);
+        lnl = res[0];
+        for (size_t k = 0; k < plan.size(); k++) sum_scale[k] = res[2 + k];
+    }
     if (!dry_run) {
         if (!engine) throw std::runtime_error("HIP likelihood kernel selected but no engine attached");
         pushInputs();

@@ -60,6 +60,7 @@ def test_no_cpu_fallback_without_gpu(pkg):
 def test_unsupported_shapes_are_rejected(pkg):
     lib = pkg.libiqhip()
     e = C.c_void_p()
-    assert lib.iqhip_create(C.byref(e), 0, 5, 4, 100, 5) == 3   # nstates 5: UNSUPPORTED
+    assert lib.iqhip_create(C.byref(e), 0, 5, 4, 100, 5) == 3   # nstates 5: UNSUPPORTED (reference: scalar kernel)
+    assert lib.iqhip_create(C.byref(e), 0, 2, 4, 100, 5) == 3   # binary data: not in scope
     assert lib.iqhip_create(C.byref(e), 0, 4, 4, 0, 5) == 2     # nptn 0: INVALID
     assert lib.iqhip_create(C.byref(e), 0, 4, 4, 10, 1) == 2    # ntaxa 1: INVALID

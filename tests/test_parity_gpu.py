@@ -310,3 +310,75 @@ def test_other_workgroup_sizes(pkg, synth, oracle, monkeypatch, wg):
     lnl = t.compute_likelihood()
     ref, _ = ot.likelihood()
     assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+
+
+# ------------------------------------------------------------------------------------------
+# 20-state (protein) and 64-state (codon) matrix-core path
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,ncat,seq_type", [(20, 4, 1), (20, 1, 1), (64, 1, 2), (64, 2, 2), (20, 5, 1)])
+def test_mfma_full_traversal(pkg, synth, oracle, n, ncat, seq_type):
+    t, ot, *_ = make_case(synth, oracle, pkg, 11, 300, n, ncat, 200 + n + ncat, seq_type=seq_type, missing=0.05)
+    t.clear_all_partial_lh()
+    lnl = t.compute_likelihood()
+    ref, (a, b) = ot.likelihood()
+    assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+    assert check_all_vectors(t, ot) == 11 - 2
+    _, plh = ot.branch_lnl(a, b)
+    np.testing.assert_allclose(t.fetch_pattern_lh(), plh, rtol=1e-10, atol=1e-10)
+    # every branch, leaf and internal forms
+    for x in range(t.num_nodes):
+        for y, _ in t.neighbors(x):
+            if x < y:
+                v = t.compute_likelihood_branch(x, y)
+                assert abs(v - ref) <= LNL_RTOL * abs(ref), (x, y)
+
+
+def test_mfma_protein_ambiguity_states(pkg, synth, oracle):
+    model = synth.random_reversible_model(20, 5, alpha=0.7, ncat=4)
+    nwk = synth.random_tree_newick(9, 6)
+    st = synth.simulate_alignment(nwk, model, 400, 7)
+    rng = np.random.default_rng(2)
+    m = rng.random(st.shape) < 0.2
+    st[m] = rng.integers(20, 24, m.sum())  # B, Z, U and unknown
+    pat, freq = synth.compress_patterns(st)
+    ot = oracle.OracleTree(nwk, 20, 1, pat, freq, None, model)
+    t = pkg.PhyloTree(nwk)
+    t.set_alignment(20, 1, pat, freq)
+    t.set_model(model)
+    t.attach_engine(0)
+    lnl = t.compute_likelihood()
+    ref, _ = ot.likelihood()
+    assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+    check_all_vectors(t, ot)
+
+
+@pytest.mark.parametrize("n,seq_type", [(20, 1), (64, 2)])
+def test_mfma_scaling_counters_bit_exact(pkg, synth, oracle, n, seq_type):
+    ncat = 4 if n == 20 else 1
+    t, ot, *_ = make_case(synth, oracle, pkg, 150, 80, n, ncat, 300 + n, seq_type=seq_type, lo=0.3, hi=0.7,
+                          caterpillar=True)
+    lnl = t.compute_likelihood()
+    ref, (a, b) = ot.likelihood()
+    _, sc, sf = ot.partial(a, b)
+    assert sc.max() >= 1 and sf < 0
+    assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+    assert check_all_vectors(t, ot) == 150 - 2
+
+
+@pytest.mark.parametrize("n,ncat,seq_type", [(20, 4, 1), (64, 1, 2)])
+def test_mfma_derivatives_and_from_buffer(pkg, synth, oracle, n, ncat, seq_type):
+    t, ot, *_ = make_case(synth, oracle, pkg, 9, 350, n, ncat, 400 + n, seq_type=seq_type, missing=0.03)
+    t.compute_likelihood()
+    for (a, b) in [(0, t.neighbors(0)[0][0]), (t.num_leaves, t.neighbors(t.num_leaves)[1][0])]:
+        t.reset_theta()
+        df, ddf = t.compute_likelihood_derv(a, b)
+        odf, oddf = ot.derv(a, b)
+        assert abs(df - odf) <= 1e-9 * max(1.0, abs(odf)) + 1e-12 * abs(oddf)
+        assert abs(ddf - oddf) <= 1e-9 * abs(oddf)
+        v = t.compute_likelihood_from_buffer()
+        o, _ = ot.lnl_from_theta(a, b)
+        assert abs(v - o) <= LNL_RTOL * abs(o)
+    opt = t.optimize_all_branches(iterations=3, tolerance=1e-3)
+    ot2 = oracle.OracleTree(t.tree_string(), n, seq_type, ot.states, ot.freq, None, ot.model)
+    ref, _ = ot2.likelihood()
+    assert abs(opt - ref) <= 1e-8 * abs(ref)
