@@ -25,6 +25,9 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# fp64 matrix peak: the guide's MFMA table has no f64 row; MI355X datasheet value,
+# equal to the fp64 vector peak on this chip
+MFMA_F64_PEAK_TFLOPS = 78.6
 
 
 def algorithmic_bytes_per_traversal(ntaxa, nptn, block):
@@ -33,13 +36,22 @@ def algorithmic_bytes_per_traversal(ntaxa, nptn, block):
     return nptn * ((2 * ntaxa - 4) * V + (2 * ntaxa - 4) * 2 + ntaxa + 8 + 16)
 
 
+def algorithmic_flops_per_traversal(ntaxa, nptn, n, ncat):
+    """SURVEY.md 8(d) per-update flops summed over a traversal rooted at a leaf branch:
+    T-2 updates each pay the U^-1 product + Hadamard (2n^2+n), T-3 internal children each pay one
+    E*v product (2n^2); leaf children are table look-ups in the reference (0 flops)."""
+    return nptn * ncat * ((ntaxa - 2) * (2 * n * n + n) + (ntaxa - 3) * 2 * n * n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--ntaxa", type=int, default=50)
-    ap.add_argument("--patterns", type=int, default=100000, help="patterns per GPU")
+    ap.add_argument("--workload", choices=["dna", "protein", "codon"], default="dna",
+                    help="dna = BASELINE configs[1] (the headline); protein/codon = configs[2]/[4] shapes")
+    ap.add_argument("--ntaxa", type=int, default=0)
+    ap.add_argument("--patterns", type=int, default=0, help="patterns per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -67,9 +79,18 @@ def main():
     synth = importlib.import_module("iqtree_amd.synth")
     lib = pkg.libiqhip()
 
-    T, P = args.ntaxa, args.patterns
-    model = synth.gtr_model(rates6=(1.5, 2.4, 1.8, 1.9, 2.8, 1.0), freqs=(0.25, 0.26, 0.25, 0.24),
-                            alpha=0.9, ncat=4)
+    shapes = {"dna": (50, 100000, 4, 4, pkg.SEQ_DNA), "protein": (100, 50000, 20, 4, pkg.SEQ_PROTEIN),
+              "codon": (50, 20000, 64, 1, pkg.SEQ_CODON)}
+    T0, P0, nst, ncat, seq_type = shapes[args.workload]
+    T, P = args.ntaxa or T0, args.patterns or P0
+    if nst == 4:
+        model = synth.gtr_model(rates6=(1.5, 2.4, 1.8, 1.9, 2.8, 1.0), freqs=(0.25, 0.26, 0.25, 0.24),
+                                alpha=0.9, ncat=4)
+    else:
+        # random reversible 20-/64-state model of the LG+G4 / GY shape (the reference's empirical
+        # matrices are constants of its source and are not copied); codon: ncat = 1 as GY+F1X4
+        model = synth.random_reversible_model(nst, 7, alpha=0.9 if ncat > 1 else None, ncat=ncat,
+                                              min_freq=1e-4)
     # same tree on every rank (seed 1); each rank simulates its own shard of sites
     nwk = synth.random_tree_newick(T, 1)
     nsites = int(P * 1.02) + 64
@@ -83,7 +104,7 @@ def main():
     freq = freq[:P].copy()
 
     tree = pkg.PhyloTree(nwk)
-    tree.set_alignment(4, pkg.SEQ_DNA, pat, freq)
+    tree.set_alignment(nst, seq_type, pat, freq)
     tree.set_model(model)
     tree.set_likelihood_kernel(pkg.LK_EIGEN_HIP)
     tree.attach_engine(local_rank)
@@ -127,11 +148,24 @@ def main():
 
     updates = args.steps * (T - 2) * P * world
     value = updates / dt / 1e6
-    block = 4 * model.ncat
+    block = nst * model.ncat
     algo_bytes = algorithmic_bytes_per_traversal(T, P, block)
     kern_s = avg_ms.value * 1e-3
     achieved = algo_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
 
+    algo_flops = algorithmic_flops_per_traversal(T, P, nst, model.ncat)
+    if nst == 64:
+        tf = algo_flops / kern_s / 1e12 if kern_s > 0 else 0.0
+        roof = {"bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / MFMA_F64_PEAK_TFLOPS, "traffic": None,
+                "algorithmic_flops_per_launch": algo_flops, "algorithmic_GBps": achieved}
+    else:
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "algorithmic_TFLOPs": algo_flops / kern_s / 1e12 if kern_s > 0 else 0.0}
+    roof.update({"kernel": "k_traverse4<4,256>" if nst == 4 else "k_traverse_mfma<%d,256>" % nst,
+                 "kernel_avg_ms": avg_ms.value, "launches": launches.value})
     out = {
         "metric": "million pattern-node partial-likelihood updates/sec",
         "value": value,
@@ -145,21 +179,18 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "DNA %d taxa x %d patterns/GPU, GTR+G4, fixed tree: clearAllPartialLH + "
-                               "full traversal + root-branch lnL" % (T, P),
-                   "ntaxa": T, "patterns_per_gpu": P, "nstates": 4, "ncat": 4,
+        "config": {"workload": "%s %d taxa x %d patterns/GPU, %s, fixed tree: clearAllPartialLH + "
+                               "full traversal + root-branch lnL" % (args.workload.upper(), T, P, model.name),
+                   "ntaxa": T, "patterns_per_gpu": P, "nstates": nst, "ncat": model.ncat,
                    "parallelism": "patterns sharded over %d GPU(s), 1 RCCL all-reduce/step" % world},
         "lnL": lnl,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_traverse4<4>", "kernel_avg_ms": avg_ms.value,
-                     "launches": launches.value, "algorithmic_bytes_per_launch": algo_bytes},
+        "roofline": roof,
     }
 
     if rank == 0 and not args.no_cpu_baseline:
         od = entry.load_oracle()
-        sample = min(P, 20000)
-        ot = od.OracleTree(nwk, 4, od.SEQ_DNA, pat[:, :sample], freq[:sample], None, model)
+        sample = min(P, 20000 if nst == 4 else 2000)
+        ot = od.OracleTree(nwk, nst, seq_type, pat[:, :sample], freq[:sample], None, model)
         mups, reps, secs = ot.time_traversals(budget_s=args.cpu_seconds)
         # parity of the timed configuration itself, on the sample
         olnl, _ = ot.likelihood()
