@@ -109,11 +109,15 @@ def main():
     tree.set_likelihood_kernel(pkg.LK_EIGEN_HIP)
     tree.attach_engine(local_rank)
     eng = tree.engine
-    stream = torch.cuda.current_stream()
-    assert lib.iqhip_set_stream(eng, C.c_void_p(stream.cuda_stream)) == 0
-    res = torch.zeros(2 + 4096, dtype=torch.float64, device="cuda")
-    assert lib.iqhip_bind_result_buffer(eng, C.c_void_p(res.data_ptr()), res.numel()) == 0
+    res = None
     if world > 1:
+        # sharded run: the engine works on torch's current stream and leaves each result vector in a
+        # torch-owned device buffer, which is all-reduced over RCCL before the single host read
+        stream = torch.cuda.current_stream()
+        assert lib.iqhip_set_stream(eng, C.c_void_p(stream.cuda_stream)) == 0
+        res = torch.zeros(2 + 4096, dtype=torch.float64, device="cuda")
+        assert lib.iqhip_bind_result_buffer(eng, C.c_void_p(res.data_ptr()), res.numel()) == 0
+
         def hook(ptr, n):
             assert ptr == res.data_ptr()
             dist.all_reduce(res[:n], op=dist.ReduceOp.SUM)

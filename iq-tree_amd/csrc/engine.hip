@@ -65,6 +65,8 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     e->ntaxa = ntaxa;
     e->nptn = nptn;
     e->mfma = nstates != 4;
+    e->mfma_pipelined = ((nstates == 20 && (ncat == 4 || ncat == 1)) || (nstates == 64 && ncat == 1)) &&
+                        !getenv("IQHIP_MFMA_V1");
     e->tile = e->mfma ? 16 : 64;
     e->block = nstates * ncat;
     e->nptn_pad = round_up(nptn, 64);
@@ -97,8 +99,11 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
               dmalloc(&e->d_theta, P * e->block) == hipSuccess &&
               dmalloc(&e->d_pattern_lh, P) == hipSuccess;
     e->result_cap = 2 + 4096;
-    ok = ok && dmalloc(&e->d_result_own, e->result_cap) == hipSuccess &&
-         hipHostMalloc((void **)&e->h_result, e->result_cap * sizeof(double)) == hipSuccess &&
+    // default result buffer: pinned host memory mapped into the device address space -- the
+    // reduction kernel writes the handful of result doubles straight to the host (no D2H copy
+    // on the critical path); a caller-bound device buffer (RCCL) replaces it
+    ok = ok && hipHostMalloc((void **)&e->h_result, e->result_cap * sizeof(double), hipHostMallocMapped) == hipSuccess &&
+         hipHostGetDevicePointer((void **)&e->d_result_own, e->h_result, 0) == hipSuccess &&
          hipEventCreateWithFlags(&e->staging_free, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         iqhip_destroy(e);
@@ -114,7 +119,7 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     e->d_result = e->d_result_own;
     hipMemsetAsync(e->d_theta, 0, P * e->block * sizeof(double), e->stream);
     hipMemsetAsync(e->d_pattern_lh, 0, P * sizeof(double), e->stream);
-    hipMemsetAsync(e->d_result_own, 0, e->result_cap * sizeof(double), e->stream);
+    memset(e->h_result, 0, e->result_cap * sizeof(double));
     hipStreamSynchronize(e->stream);
     *out = e;
     return IQHIP_OK;
@@ -130,7 +135,7 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
     }
     void *ptrs[] = {e->d_states, e->d_freq, e->d_invar, e->d_eval, e->d_evec, e->d_inv_evec,
                     e->d_rates, e->d_props, e->d_tip, e->d_ops, e->d_val, e->d_slab,
-                    e->d_theta, e->d_pattern_lh, e->d_result_own, e->dummy.plh, e->dummy.sc};
+                    e->d_theta, e->d_pattern_lh, e->dummy.plh, e->dummy.sc};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (e->h_ops) hipHostFree(e->h_ops);
@@ -315,6 +320,7 @@ static int ensure_plan_capacity(iqhip_engine *e, int nops) {
     if (e->d_ops) hipFree(e->d_ops);
     if (e->h_ops) hipHostFree(e->h_ops);
     e->d_ops = nullptr; e->h_ops = nullptr; e->ops_cap = 0;
+    e->uploaded_plan.clear();
     HIPCHK(dmalloc(&e->d_ops, cap));
     HIPCHK(hipHostMalloc((void **)&e->h_ops, sizeof(DevOp) * cap));
     e->ops_cap = cap;
@@ -406,8 +412,8 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         double llen = o.left_len, rlen = o.right_len;
         d.dst = e->slabs[didx].plh;
         d.dst_sc = e->slabs[didx].sc;
-        if (e->mfma) {
-            // matrix-core path: both children are read from memory (pf = left, ld = right)
+        if (e->mfma && !e->mfma_pipelined) {
+            // generic matrix-core kernel: both children are read from memory (pf = left, ld = right)
             if (lkind != CHILD_LEAF) { lkind = CHILD_LOAD; d.pf = lp; d.pf_sc = lsc; } else d.sl = lst;
             if (rkind != CHILD_LEAF) { rkind = CHILD_LOAD; d.ld = rp; d.ld_sc = rsc; } else d.sr = rst;
         } else {
@@ -443,7 +449,8 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         if (e->mfma) {
             const int MT = (e->n + 15) / 16, KS = e->n / 4;
             const int fixed = 2 * MT * KS * 64 + (e->state_unknown + 1 - e->n) * e->n;
-            budget = (150 * 1024) / 8 - fixed;
+            // two workgroups per CU (160 KB LDS): <= 78 KB each, images included
+            budget = (78 * 1024) / 8 - fixed;
         } else {
             budget = (e->lds_budget_bytes / 8) - 128 - B;
         }
@@ -467,10 +474,15 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         if (nops > 0) e->h_ops[chunk_start].chunk_nops = nops - chunk_start;
         e->plan_lds_doubles = max_used;
     }
-    HIPCHK(hipMemcpyAsync(e->d_ops, e->h_ops, sizeof(DevOp) * (nops + kSentinels), hipMemcpyHostToDevice,
-                          e->stream));
+    // the descriptors of a repeated plan (model-parameter optimisation re-evaluates the same
+    // tree) are already on the device: skip the upload, never the computation
+    const size_t nbytes = sizeof(DevOp) * (size_t)(nops + kSentinels);
+    if (e->uploaded_plan.size() == nbytes && memcmp(e->uploaded_plan.data(), e->h_ops, nbytes) == 0)
+        return IQHIP_OK;
+    HIPCHK(hipMemcpyAsync(e->d_ops, e->h_ops, nbytes, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipEventRecord(e->staging_free, e->stream));
     e->staging_busy = true;
+    e->uploaded_plan.assign((const char *)e->h_ops, (const char *)e->h_ops + nbytes);
     return IQHIP_OK;
 }
 
@@ -535,8 +547,9 @@ static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, 
 }
 
 static int read_result(iqhip_engine *e, int ndoubles) {
-    HIPCHK(hipMemcpyAsync(e->h_result, e->d_result, sizeof(double) * ndoubles, hipMemcpyDeviceToHost,
-                          e->stream));
+    if (e->d_result != e->d_result_own)  // caller-bound device buffer
+        HIPCHK(hipMemcpyAsync(e->h_result, e->d_result, sizeof(double) * ndoubles, hipMemcpyDeviceToHost,
+                              e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->staging_busy = false;
     return IQHIP_OK;

@@ -73,6 +73,7 @@ struct iqhip_engine {
     int64_t ntiles = 0;    // tiles of `tile` patterns
     int tile = 64;         // 64 (VALU path) or 16 (MFMA path)
     bool mfma = false;     // nstates 20 / 64: matrix-core path (kernels_mfma.hip)
+    bool mfma_pipelined = false;  // (n, ncat) has a k_traverse_mfma2 instantiation (IQHIP_MFMA_V1=1 disables)
     int wg_size = 256;     // threads per workgroup of the traversal kernel (IQHIP_WG env)
     int ablate = 0;        // IQHIP_ABLATE: timing-only host-side switches (results wrong when set)
     int lds_budget_bytes = 64 * 1024;  // per-workgroup LDS for the per-branch regions (IQHIP_LDS_KB)
@@ -105,6 +106,7 @@ struct iqhip_engine {
     // pinned host staging
     iqhip::DevOp *h_ops = nullptr;
     double *h_result = nullptr;
+    std::vector<char> uploaded_plan;  // bytes of the descriptors currently in d_ops
     hipEvent_t staging_free = nullptr;
     bool staging_busy = false;
 

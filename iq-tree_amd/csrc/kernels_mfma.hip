@@ -193,6 +193,222 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Pipelined variant (compile-time category count).  Differences from k_traverse_mfma:
+//   * the previous op's result stays in registers: its accumulator image IS the B operand of
+//     the next op (CHILD_PREV), consumed and overwritten in place category by category;
+//   * the streamed child (CHILD_PF) of the next (op, category) step is requested one step ahead
+//     (unconditional request folded onto a dummy window when not needed, as in k_traverse4);
+//   * for N = 20 the A fragments of U and U^-1 (2 x 10 doubles) live in registers for the whole
+//     launch; for N = 64 they are read from the LDS image next to the MFMA that uses them.
+// Host canonical form as for DNA: left in {LEAF, PF}, right in {LEAF, PREV}; (PF, LOAD) reads the
+// right child synchronously into the `prev` registers.
+// ---------------------------------------------------------------------------------------
+template <int N, int C, int WG>
+__global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
+    constexpr int MT = (N + 15) / 16;
+    constexpr int KS = N / 4;
+    constexpr int WPB = WG / 64;
+    constexpr int B = C * N;
+    constexpr bool A_IN_REGS = false;  // A fragments from the LDS image: registers buy occupancy 2
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *sU = smem;
+    double *sUi = sU + MT * KS * 64;
+    double *sTipx = sUi + MT * KS * 64;
+    const int nx = A.state_unknown + 1 - N;
+    double *sReg = sTipx + nx * N;
+
+    for (int t = threadIdx.x; t < MT * KS * 64; t += WG) {
+        const int l = t & 63, ms = t >> 6, s = ms % KS, m = ms / KS;
+        const int row = 16 * m + (l & 15), k = 4 * s + (l >> 4);
+        sU[t] = row < N ? A.evec[row * N + k] : 0.0;
+        sUi[t] = row < N ? A.inv_evec[row * N + k] : 0.0;
+    }
+    for (int t = threadIdx.x; t < nx * N; t += WG) sTipx[t] = A.tip[N * N + t];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * WPB + wave;
+    const bool active = tile < A.ntiles;
+    const int64_t tl = active ? tile : 0;
+    const int p = lane & 15, g = lane >> 4;
+    const int64_t ptn = tl * 16 + p;
+    const size_t tbase = (size_t)tl * 16 * B;     // doubles into a vector slab
+    const size_t dbase = (size_t)lane;            // dummy window: first tile only
+    const double freq = A.freq[ptn];
+    const double invar = A.invar[ptn];
+    const DevOp *ops = A.ops;
+
+    v4f64 prev[C][MT];
+#pragma unroll
+    for (int c = 0; c < C; c++)
+#pragma unroll
+        for (int m = 0; m < MT; m++) prev[c][m] = (v4f64){0, 0, 0, 0};
+    int prev_sc = 0;
+    double PFn[KS];
+    int pfn_sc = 0;
+    {   // prime: streamed child of (op 0, category 0); ops[nops..] are sentinels
+        const double *src = ops[0].pf + ((ops[0].real_mask & 1) ? tbase : 0);
+#pragma unroll
+        for (int s = 0; s < KS; s++) PFn[s] = src[s * 64 + lane];
+        if (g == 0) pfn_sc = ops[0].pf_sc[(ops[0].real_mask & 1) ? ptn : (int64_t)p];
+    }
+
+    double aU[A_IN_REGS ? MT * KS : 1], aUi[A_IN_REGS ? MT * KS : 1];
+    __syncthreads();
+    if (A_IN_REGS) {
+#pragma unroll
+        for (int q = 0; q < MT * KS; q++) {
+            aU[q] = sU[q * 64 + lane];
+            aUi[q] = sUi[q * 64 + lane];
+        }
+    }
+
+    int k = 0;
+    while (k < A.nops) {
+        const int kn = ops[k].chunk_nops;
+        __syncthreads();
+        for (int t = threadIdx.x; t < kn * 2 * B; t += WG) {
+            const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B;
+            const DevOp &d = ops[k + o];
+            const double len = child ? d.right_len : d.left_len;
+            sReg[(child ? d.lds_right : d.lds_left) + e] = exp(A.eval[e % N] * (A.rates[e / N] * len));
+        }
+        __syncthreads();
+        if (!active) { k += kn; continue; }
+
+        for (int kk = 0; kk < kn; kk++, k++) {
+            const DevOp &op = ops[k];
+            const DevOp &nxop = ops[k + 1];
+            const bool leafL = op.left_kind == CHILD_LEAF, leafR = op.right_kind == CHILD_LEAF;
+            const double *exL = sReg + op.lds_left, *exR = sReg + op.lds_right;
+            int sc = 0, sL = 0, sR = 0;
+            if (leafL) sL = op.sl[ptn]; else sc += pfn_sc;          // pfn_sc: valid on g == 0 lanes
+            if (leafR) sR = op.sr[ptn];
+            if (op.right_kind == CHILD_LOAD) {
+                // rare (PF, LOAD): read the right child now into the `prev` registers
+                const double *src = op.ld + tbase;
+#pragma unroll
+                for (int c = 0; c < C; c++)
+#pragma unroll
+                    for (int s = 0; s < KS; s++) prev[c][s >> 2][s & 3] = src[(size_t)c * N * 16 + s * 64 + lane];
+                if (g == 0) prev_sc = op.ld_sc[ptn];
+            }
+            if (!leafR) sc += prev_sc;
+            const bool unkL = leafL && sL == A.state_unknown, unkR = leafR && sR == A.state_unknown;
+            const double *vnow = op.pf + ((op.real_mask & 1) ? tbase : dbase * 0);
+            (void)vnow;
+            double *dst = op.dst + tbase;
+            double lmax = 0.0;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                double bl[KS], br[KS];
+#pragma unroll
+                for (int s = 0; s < KS; s++) bl[s] = PFn[s];
+                // request the streamed child of the next step: (k, c+1) or (k+1, 0)
+                {
+                    const DevOp &nd = (c + 1 < C) ? op : nxop;
+                    const int nc = (c + 1 < C) ? c + 1 : 0;
+                    const bool real = nd.real_mask & 1;
+                    const double *src = nd.pf + (real ? tbase + (size_t)nc * N * 16 : 0);
+#pragma unroll
+                    for (int s = 0; s < KS; s++) PFn[s] = src[s * 64 + lane];
+                    if (c + 1 == C && g == 0) pfn_sc = nd.pf_sc[real ? ptn : (int64_t)p];
+                }
+                if (leafL) {
+#pragma unroll
+                    for (int s = 0; s < KS; s++) {
+                        const int i = 4 * s + g;
+                        bl[s] = sL < N ? sUi[aidx<KS>(i >> 4, sL >> 2, (sL & 3) * 16 + (i & 15))] : sTipx[(sL - N) * N + i];
+                    }
+                }
+                if (leafR) {
+#pragma unroll
+                    for (int s = 0; s < KS; s++) {
+                        const int i = 4 * s + g;
+                        br[s] = sR < N ? sUi[aidx<KS>(i >> 4, sR >> 2, (sR & 3) * 16 + (i & 15))] : sTipx[(sR - N) * N + i];
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < KS; s++) br[s] = prev[c][s >> 2][s & 3];
+                }
+                v4f64 YL[MT], YR[MT];
+#pragma unroll
+                for (int m = 0; m < MT; m++) { YL[m] = (v4f64){0, 0, 0, 0}; YR[m] = (v4f64){0, 0, 0, 0}; }
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    const int i = 4 * s + g;
+                    const double xl = bl[s] * exL[c * N + i];
+                    const double xr = br[s] * exR[c * N + i];
+#pragma unroll
+                    for (int m = 0; m < MT; m++) {
+                        const double a = A_IN_REGS ? aU[A_IN_REGS ? m * KS + s : 0] : sU[aidx<KS>(m, s, lane)];
+                        YL[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xl, YL[m], 0, 0, 0);
+                        YR[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xr, YR[m], 0, 0, 0);
+                    }
+                }
+                v4f64 T[MT];
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const double a = unkL ? 1.0 : YL[m][r];
+                        const double b = unkR ? 1.0 : YR[m][r];
+                        T[m][r] = a * b;
+                    }
+                v4f64 O[MT];
+#pragma unroll
+                for (int m = 0; m < MT; m++) O[m] = (v4f64){0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    const double bt = T[s >> 2][s & 3];
+#pragma unroll
+                    for (int m = 0; m < MT; m++) {
+                        const double a = A_IN_REGS ? aUi[A_IN_REGS ? m * KS + s : 0] : sUi[aidx<KS>(m, s, lane)];
+                        O[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bt, O[m], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < MT; m++) {
+                    prev[c][m] = O[m];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        if (16 * m + 4 * r < N) {
+                            const int row = 16 * m + 4 * r + g;
+                            dst[(size_t)(c * N + row) * 16 + p] = O[m][r];
+                            lmax = fmax(lmax, fabs(O[m][r]));
+                        }
+                    }
+                }
+            }
+            lmax = fmax(lmax, __shfl_xor(lmax, 16, 64));
+            lmax = fmax(lmax, __shfl_xor(lmax, 32, 64));
+            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0);
+            double my_scale = 0.0;
+            if (__any(do_scale)) {
+                if (do_scale) {
+#pragma unroll
+                    for (int c = 0; c < C; c++)
+#pragma unroll
+                        for (int m = 0; m < MT; m++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                prev[c][m][r] *= kScalingThresholdInv;
+                                if (16 * m + 4 * r < N)
+                                    dst[(size_t)(c * N + 16 * m + 4 * r + g) * 16 + p] = prev[c][m][r];
+                            }
+                    sc += 1;
+                    if (g == 0 && ptn < A.nptn) my_scale = kLogScalingThreshold * freq;
+                }
+            }
+            prev_sc = sc;
+            if (g == 0) op.dst_sc[ptn] = (int16_t)sc;
+            const double ws = wave_sum_m(my_scale);
+            if (lane == 0) A.slab[(size_t)(2 + k) * A.nwaves + (int)tl] = ws;
+        }
+    }
+}
+
 template <int N>
 static hipError_t launch_trav_m(iqhip_engine *e, TravMArgs &A) {
     constexpr int MT = (N + 15) / 16, KS = N / 4, WG = 256;
@@ -206,6 +422,22 @@ static hipError_t launch_trav_m(iqhip_engine *e, TravMArgs &A) {
     }
     const int grid = (int)((A.ntiles + 3) / 4);
     hipLaunchKernelGGL((k_traverse_mfma<N, WG>), dim3(grid), dim3(WG), lds, e->stream, A);
+    return hipGetLastError();
+}
+
+template <int N, int C>
+static hipError_t launch_trav_m2(iqhip_engine *e, TravMArgs &A) {
+    constexpr int MT = (N + 15) / 16, KS = N / 4, WG = 256;
+    const int nx = e->state_unknown + 1 - N;
+    const size_t lds = (size_t)(2 * MT * KS * 64 + nx * N + e->plan_lds_doubles) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma2<N, C, WG>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int grid = (int)((A.ntiles + 3) / 4);
+    hipLaunchKernelGGL((k_traverse_mfma2<N, C, WG>), dim3(grid), dim3(WG), lds, e->stream, A);
     return hipGetLastError();
 }
 
@@ -227,6 +459,12 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, int nops, int nwaves) {
     A.ncat = e->ncat;
     A.state_unknown = e->state_unknown;
     if (nops <= 0) return hipSuccess;
+    if (e->mfma_pipelined) {  // plan was built in canonical (PF, PREV) form
+        if (e->n == 20 && e->ncat == 4) return launch_trav_m2<20, 4>(e, A);
+        if (e->n == 20 && e->ncat == 1) return launch_trav_m2<20, 1>(e, A);
+        if (e->n == 64 && e->ncat == 1) return launch_trav_m2<64, 1>(e, A);
+        return hipErrorInvalidValue;
+    }
     switch (e->n) {
         case 20: return launch_trav_m<20>(e, A);
         case 64: return launch_trav_m<64>(e, A);
