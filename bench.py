@@ -168,6 +168,15 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "algorithmic_TFLOPs": algo_flops / kern_s / 1e12 if kern_s > 0 else 0.0}
+    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    # (tools/profile_round.sh -> profiles/traffic.json); null when the shape was not profiled
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(args.workload)
+        if tr and tr["ntaxa"] == T and tr["patterns_per_gpu"] == P and tr["ncat"] == model.ncat:
+            roof["traffic"] = tr["hbm_traffic_bytes_per_launch"]
+            roof["traffic_source"] = tr["source"]
+    except Exception:
+        pass
     roof.update({"kernel": "k_traverse4<4,256>" if nst == 4 else "k_traverse_mfma<%d,256>" % nst,
                  "kernel_avg_ms": avg_ms.value, "launches": launches.value})
     out = {
