@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--patterns", type=int, default=0, help="patterns per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reference-order", action="store_true",
+                    help="plan subtrees in the reference's neighbour order instead of heavier-first")
     args = ap.parse_args()
 
     import torch
@@ -107,6 +109,8 @@ def main():
     tree.set_alignment(nst, seq_type, pat, freq)
     tree.set_model(model)
     tree.set_likelihood_kernel(pkg.LK_EIGEN_HIP)
+    if args.reference_order:
+        tree.set_heavy_first(False)
     tree.attach_engine(local_rank)
     eng = tree.engine
     res = None
@@ -135,13 +139,17 @@ def main():
 
     for _ in range(args.warmup):
         lnl = step()
-    lib.iqhip_timing_enable(eng, 1)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         lnl = step()
     barrier()
     dt = time.perf_counter() - t0
+    # dominant-kernel duration: HIP events on the launch stream around that kernel, measured live in
+    # a second pass of the same steps (kept out of the timed region: two event records per step)
+    lib.iqhip_timing_enable(eng, 1)
+    for _ in range(min(args.steps, 100)):
+        step()
     avg_ms, launches = C.c_double(), C.c_int64()
     lib.iqhip_timing_read(eng, C.byref(avg_ms), C.byref(launches), 1)
     lib.iqhip_timing_enable(eng, 0)

@@ -131,6 +131,7 @@ def libiqhost():
     lib.iqhost_set_kernel.argtypes = [vp, C.c_int]
     lib.iqhost_attach_engine.argtypes = [vp, C.c_int]
     lib.iqhost_set_dry_run.argtypes = [vp, C.c_int]
+    lib.iqhost_set_heavy_first.argtypes = [vp, C.c_int]
     lib.iqhost_engine.argtypes = [vp]
     lib.iqhost_engine.restype = vp
     lib.iqhost_set_allreduce_hook.argtypes = [vp, ALLREDUCE_HOOK, vp]
@@ -236,6 +237,9 @@ class PhyloTree:
 
     def attach_engine(self, device=0):
         self._chk(self.lib.iqhost_attach_engine(self.h, device))
+
+    def set_heavy_first(self, on=True):
+        self._chk(self.lib.iqhost_set_heavy_first(self.h, int(on)))
 
     def set_dry_run(self, on=True):
         self._chk(self.lib.iqhost_set_dry_run(self.h, int(on)))

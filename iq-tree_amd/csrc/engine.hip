@@ -369,7 +369,7 @@ static int resolve_child(iqhip_engine *e, uint64_t key, int32_t leaf, int prev_d
 }
 
 static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *last_dst) {
-    constexpr int kSentinels = 4;  // >= the kernel's deepest look-ahead (leaf states: 4 ops)
+    constexpr int kSentinels = 2;  // >= the kernels' deepest look-ahead (streamed child: 1 op)
     if (nops + 2 > e->result_cap) return fail(IQHIP_ERR_INVALID, "too many node updates in one submission");
     int rc = ensure_plan_capacity(e, nops + kSentinels);
     if (rc) return rc;
@@ -430,10 +430,9 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
             if (rkind == CHILD_LOAD) e->plan_has_load = true;                      // (PF, LOAD)
             if (lkind == CHILD_PF) { d.pf = lp; d.pf_sc = lsc; d.real_mask |= 1; }
             if (rkind == CHILD_LOAD) { d.ld = rp; d.ld_sc = rsc; }
-            if (lkind == CHILD_LEAF) { d.sl = lst; d.real_mask |= 2; }
-            if (rkind == CHILD_LEAF) { d.sr = rst; d.real_mask |= 4; }
+            if (lkind == CHILD_LEAF) d.sl = lst;
+            if (rkind == CHILD_LEAF) d.sr = rst;
             if (e->ablate & 1) d.real_mask &= ~1;  // timing-only: never stream a child (results wrong)
-            if (e->ablate & 2) d.real_mask &= ~6;  // timing-only: never read leaf states
         }
         d.left_kind = lkind;
         d.right_kind = rkind;
@@ -454,23 +453,32 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         } else {
             budget = (e->lds_budget_bytes / 8) - 128 - B;
         }
-        int chunk_start = 0, used = 0, max_used = 0;
+        int chunk_start = 0, used = e->mfma ? 0 : e->wg_size / 8, regs = 0, max_used = 0, slots = 1, max_slots = 1;
         for (int k = 0; k < nops; k++) {
             DevOp &d = e->h_ops[k];
             const int szl = (!e->mfma && d.left_kind == CHILD_LEAF) ? 6 * B : B;
             const int szr = (!e->mfma && d.right_kind == CHILD_LEAF) ? 6 * B : B;
-            const int need = szl + szr;
+            // 4-state path: each leaf child also stages one state byte per thread in LDS
+            const int nleaf = (d.left_kind == CHILD_LEAF) + (d.right_kind == CHILD_LEAF);
+            const int need = szl + szr + (e->mfma ? 0 : nleaf * e->wg_size / 8);
             if (need > budget) return fail(IQHIP_ERR_UNSUPPORTED, "nstates*ncat too large for the LDS plan regions");
             if (used + need > budget && k > chunk_start) {
                 e->h_ops[chunk_start].chunk_nops = k - chunk_start;
                 chunk_start = k;
-                used = 0;
+                used = e->mfma ? 0 : e->wg_size / 8;  // slot 0
+                regs = 0;
+                slots = 1;
             }
-            d.lds_left = used;
-            d.lds_right = used + szl;
+            d.lds_left = regs;
+            d.lds_right = regs + szl;
+            regs += szl + szr;
             used += need;
-            if (used > max_used) max_used = used;
+            if (regs > max_used) max_used = regs;
+            d.sl_slot = d.left_kind == CHILD_LEAF ? slots++ : 0;
+            d.sr_slot = d.right_kind == CHILD_LEAF ? slots++ : 0;
+            if (slots > max_slots) max_slots = slots;
         }
+        e->plan_state_slots = max_slots;
         if (nops > 0) e->h_ops[chunk_start].chunk_nops = nops - chunk_start;
         e->plan_lds_doubles = max_used;
     }

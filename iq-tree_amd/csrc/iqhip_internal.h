@@ -45,7 +45,10 @@ struct __attribute__((aligned(16))) DevOp {
     int32_t lds_left;   // offset (doubles) of the child's LDS region inside the chunk:
     int32_t lds_right;  //   internal child: [ex B]; leaf child: [ex B][table 5B]
     int32_t chunk_nops; // > 0 on the first op of an LDS chunk: number of ops in the chunk
-    int32_t real_mask;  // bit0: pf/pf_sc are real, bit1: sl is real, bit2: sr is real (else dummies)
+    int32_t real_mask;  // bit0: pf/pf_sc are real (else dummies)
+    int32_t sl_slot;    // LDS slot of the staged leaf states of the left / right child within
+    int32_t sr_slot;    //   the chunk (slot 0 is shared by all non-leaf children)
+    int32_t _pad[2];
 };
 
 // Root branch descriptor for the lnL / theta kernels.
@@ -78,6 +81,7 @@ struct iqhip_engine {
     int ablate = 0;        // IQHIP_ABLATE: timing-only host-side switches (results wrong when set)
     int lds_budget_bytes = 64 * 1024;  // per-workgroup LDS for the per-branch regions (IQHIP_LDS_KB)
     int plan_lds_doubles = 0;
+    int plan_state_slots = 1;    // leaf-state LDS slots of the largest chunk (4-state path)
     bool plan_has_load = false;  // some op has two memory children (slow kernel instantiation)
     iqhip::Slab dummy;           // valid target of unconditional prefetches  // LDS region size (doubles) of the largest chunk of the current plan
     int block = 0;         // n*ncat

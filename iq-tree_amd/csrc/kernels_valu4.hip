@@ -94,6 +94,7 @@ struct Trav4Args {
     int nwaves;
     int state_unknown;
     int has_root;
+    int lds_reg_doubles;  // size of the per-branch region area (largest chunk)
     DevBranch root;
 };
 
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
     double *s_tip = smem;             // [32][4]
     double *s_val = smem + 128;       // [B]
     double *s_reg = smem + 128 + B;   // per (op, child) regions of the current chunk
+    uint8_t *s_states = reinterpret_cast<uint8_t *>(s_reg + A.lds_reg_doubles);  // [slot][WG] leaf states
 
     const int nst = A.state_unknown + 1;
     for (int t = threadIdx.x; t < nst * 4; t += WG) s_tip[t] = A.tip[t];
@@ -266,12 +268,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
     const CONST_AS DevOp *ops = as_const(A.ops);
 
     double prev[B], PF[B];
-    // leaf state bytes are read once per traversal (cold HBM misses) and are pure inputs, so they
-    // are requested SD ops ahead and carried in a small register queue
-    constexpr int SD = 4;
-    int pf_sc = 0, prev_sc = 0, qL[SD], qR[SD];
-#pragma unroll
-    for (int q = 0; q < SD; q++) { qL[q] = 0; qR[q] = 0; }
+    int pf_sc = 0, prev_sc = 0;
 #pragma unroll
     for (int e = 0; e < B; e++) { prev[e] = 0.0; PF[e] = 0.0; }
 
@@ -283,12 +280,6 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
         load_vec4_off<C>(nx->pf, (nreal & 1) ? voff : (uint32_t)(lane * 16), PF);
         pf_sc = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(nx->pf_sc) +
                                                    ((nreal & 1) ? soff : (uint32_t)(lane * 2)));
-#pragma unroll
-        for (int q = 0; q < SD; q++) {  // ops[nops .. nops+SD) are sentinels
-            const int qreal = ops[q].real_mask;
-            qL[q] = *(ops[q].sl + ((qreal & 2) ? poff : (uint32_t)lane));
-            qR[q] = *(ops[q].sr + ((qreal & 4) ? poff : (uint32_t)lane));
-        }
     }
 
     int k = 0;
@@ -322,6 +313,16 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
             }
             reg[B + q] = v;
         }
+        // phase 3: this thread's leaf state bytes of the whole chunk -> LDS.  They are read once per
+        // traversal (cold misses); issuing them as one burst pays the miss latency once per chunk
+        // instead of once per op and keeps the op loop's VMEM sequence short.
+        if (active) {
+            for (int o = 0; o < kn; o++) {
+                const CONST_AS DevOp *d = ops + (k + o);
+                if (d->left_kind == CHILD_LEAF) s_states[d->sl_slot * WG + threadIdx.x] = *(d->sl + poff);
+                if (d->right_kind == CHILD_LEAF) s_states[d->sr_slot * WG + threadIdx.x] = *(d->sr + poff);
+            }
+        }
         __syncthreads();
         if (!active) { k += kn; continue; }
 
@@ -330,7 +331,9 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
             const bool leafL = op->left_kind == CHILD_LEAF;
             const bool leafR = op->right_kind == CHILD_LEAF;
             int sc = 0;
-            const int sL = qL[0], sR = qR[0];
+            // leaf states were staged into LDS when the chunk was filled
+            const int sL = s_states[op->sl_slot * WG + threadIdx.x];
+            const int sR = s_states[op->sr_slot * WG + threadIdx.x];
             if (!leafL) sc += pf_sc;
             if (HAS_LOAD && op->right_kind == CHILD_LOAD) {
                 // both children come from memory: the left one was streamed into PF; the right
@@ -349,14 +352,6 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
             const char *nx_pf = reinterpret_cast<const char *>(nx->pf) + ((nreal & 1) ? voff : (uint32_t)(lane * 16));
             pf_sc = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(nx->pf_sc) +
                                                        ((nreal & 1) ? soff : (uint32_t)(lane * 2)));
-#pragma unroll
-            for (int q = 0; q + 1 < SD; q++) { qL[q] = qL[q + 1]; qR[q] = qR[q + 1]; }
-            {
-                const CONST_AS DevOp *fx = ops + (k + SD);
-                const int freal = fx->real_mask;
-                qL[SD - 1] = *(fx->sl + ((freal & 2) ? poff : (uint32_t)lane));
-                qR[SD - 1] = *(fx->sr + ((freal & 4) ? poff : (uint32_t)lane));
-            }
             char *dstp = reinterpret_cast<char *>(op->dst) + voff;
             const double lh_max = node_update4<C>(leafL, leafR, s_reg + op->lds_left, s_reg + op->lds_right,
                                                   s_tip, U, uinv, sL, sR, A.state_unknown, nx_pf, dstp, PF, prev);
@@ -428,7 +423,8 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
 template <int C, int WG, bool HAS_LOAD>
 static hipError_t launch_trav_l(iqhip_engine *e, Trav4Args &A) {
     constexpr int B = 4 * C;
-    const size_t lds = (size_t)(128 + B + (size_t)e->plan_lds_doubles) * sizeof(double);
+    const size_t lds = (size_t)(128 + B + (size_t)e->plan_lds_doubles) * sizeof(double) +
+                       (size_t)e->plan_state_slots * WG;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse4<C, WG, HAS_LOAD>),
@@ -474,6 +470,7 @@ hipError_t launch_traverse4(iqhip_engine *e, int nops, const DevBranch *root, in
     A.nwaves = nwaves;
     A.state_unknown = e->state_unknown;
     A.has_root = root ? 1 : 0;
+    A.lds_reg_doubles = e->plan_lds_doubles;
     if (root) A.root = *root; else A.root = DevBranch{nullptr, nullptr, nullptr, 0, 0, 0.0};
     switch (e->ncat) {
         case 1: return launch_trav_wg<1>(e, A);

@@ -439,8 +439,14 @@ void PhyloTree::collectPlan(PhyloNeighbor *dad_branch, PhyloNode *dad, std::vect
             if (!left) left = nb; else right = nb;
         }
     if (!left->node->isLeaf() && right->node->isLeaf()) std::swap(left, right);  // :116-121
-    if ((left->partial_lh_computed & 1) == 0) collectPlan(left, node, plan);
-    if ((right->partial_lh_computed & 1) == 0) collectPlan(right, node, plan);
+    // Visit the subtree with more pending updates first: its result then waits only for the
+    // (short) other subtree before it is consumed, i.e. it is re-read while still cache-resident.
+    // The order of independent subtrees changes no number (each update is a pure function of its
+    // children); the reference simply takes neighbour order (phylokernel.h:122-125).
+    PhyloNeighbor *first = left, *second = right;
+    if (heavy_first && countPending(right, node) > countPending(left, node)) std::swap(first, second);
+    if ((first->partial_lh_computed & 1) == 0) collectPlan(first, node, plan);
+    if ((second->partial_lh_computed & 1) == 0) collectPlan(second, node, plan);
 
     if (lh_mem_save == LM_PER_NODE && !dad_branch->partial_lh) {
         // re-orient partial_lh (:127-143): steal the vector of a child-side back neighbour
@@ -473,6 +479,14 @@ void PhyloTree::collectPlan(PhyloNeighbor *dad_branch, PhyloNode *dad, std::vect
     p.op.left_len = left->length;
     p.op.right_len = right->length;
     plan.push_back(p);
+}
+
+int PhyloTree::countPending(PhyloNeighbor *nei, PhyloNode *dad) const {
+    if ((nei->partial_lh_computed & 1) || nei->node->isLeaf()) return 0;
+    int n = 1;
+    for (PhyloNeighbor *nb : nei->node->neighbors)
+        if (nb->node != dad) n += countPending(nb, nei->node);
+    return n;
 }
 
 void PhyloTree::applyScaleFactors(const std::vector<PlanOp> &plan, const std::vector<double> &sum_scale) {

@@ -108,6 +108,7 @@ public:
     // device: >= 0 creates an engine on that GPU; dry_run records plans without any device
     void attachEngine(int device);
     void setDryRun(bool on) { dry_run = on; }
+    bool heavy_first = true;  // plan order of independent subtrees (see collectPlan)
     iqhip_engine *engine = nullptr;
     // Pattern-sharded runs (one process per GPU): when set, every host-visible result vector
     // {lnL | df,ddf | sum_scale per op} is left on the device, handed to this hook (which
@@ -160,6 +161,7 @@ private:
     // replaced by "append one op"
     void collectPlan(PhyloNeighbor *dad_branch, PhyloNode *dad, std::vector<PlanOp> &plan);
     void applyScaleFactors(const std::vector<PlanOp> &plan, const std::vector<double> &sum_scale);
+    int countPending(PhyloNeighbor *nei, PhyloNode *dad) const;
     iqhip_branch_end branchEnd(PhyloNeighbor *nei) const;
     void check(int rc, const char *what) const;
     void pushInputs();
