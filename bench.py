@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--patterns", type=int, default=0, help="patterns per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="exercise the N>1 path (RCCL all-reduce of the result vector) even with one rank")
     ap.add_argument("--reference-order", action="store_true",
                     help="plan subtrees in the reference's neighbour order instead of heavier-first")
     args = ap.parse_args()
@@ -71,8 +73,15 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the likelihood path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    real_stdout = os.dup(1)
+    if collective:
+        # RCCL prints a version banner on stdout at communicator creation: keep stdout clean for the
+        # single JSON line by pointing fd 1 at stderr until the result is printed
+        sys.stdout.flush()
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -114,7 +123,7 @@ def main():
     tree.attach_engine(local_rank)
     eng = tree.engine
     res = None
-    if world > 1:
+    if collective:
         # sharded run: the engine works on torch's current stream and leaves each result vector in a
         # torch-owned device buffer, which is all-reduced over RCCL before the single host read
         stream = torch.cuda.current_stream()
@@ -133,7 +142,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -153,7 +162,7 @@ def main():
     avg_ms, launches = C.c_double(), C.c_int64()
     lib.iqhip_timing_read(eng, C.byref(avg_ms), C.byref(launches), 1)
     lib.iqhip_timing_enable(eng, 0)
-    if world > 1:
+    if collective:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -218,9 +227,11 @@ def main():
         out["cpu_baseline"] = {"value": mups, "unit": "M updates/s", "cores": 1, "kind": "port",
                                "sample": "oracle/lh_oracle.c (gcc -O3 -mavx, 1 thread): %d traversals of the "
                                          "same tree on the first %d patterns in %.1f s" % (reps, sample, secs)}
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        print(json.dumps(out), flush=True)
+    if collective:
         dist.destroy_process_group()
 
 

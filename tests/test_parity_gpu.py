@@ -382,3 +382,44 @@ def test_mfma_derivatives_and_from_buffer(pkg, synth, oracle, n, ncat, seq_type)
     ot2 = oracle.OracleTree(t.tree_string(), n, seq_type, ot.states, ot.freq, None, ot.model)
     ref, _ = ot2.likelihood()
     assert abs(opt - ref) <= 1e-8 * abs(ref)
+
+
+def test_rccl_allreduce_hook_single_rank(pkg, synth, oracle):
+    """The N>1 plumbing of bench.py on one GPU: engine on torch's stream, result vector left in a
+    torch-owned device buffer, all-reduced with the nccl(=RCCL) backend (world_size 1) inside the
+    host mirror's hook, then read back.  Must give the same numbers as the synchronous path."""
+    import os
+    import torch
+    import torch.distributed as dist
+    t, ot, *_ = make_case(synth, oracle, pkg, 12, 900, 4, 4, 111, missing=0.03)
+    ref_lnl = t.compute_likelihood()
+    a, b = t.current_branch()
+    ref_df, ref_ddf = t.compute_likelihood_derv(a, b)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        lib = pkg.libiqhip()
+        res = torch.zeros(2 + 4096, dtype=torch.float64, device="cuda")
+        stream = torch.cuda.current_stream()
+        assert lib.iqhip_set_stream(t.engine, C.c_void_p(stream.cuda_stream)) == 0
+        assert lib.iqhip_bind_result_buffer(t.engine, C.c_void_p(res.data_ptr()), res.numel()) == 0
+        calls = []
+
+        def hook(ptr, n):
+            assert ptr == res.data_ptr()
+            calls.append(n)
+            dist.all_reduce(res[:n], op=dist.ReduceOp.SUM)
+        t.set_allreduce_hook(hook)
+        for _ in range(3):
+            t.clear_all_partial_lh()
+            lnl = t.compute_likelihood()
+            assert lnl == ref_lnl
+        t.reset_theta()
+        df, ddf = t.compute_likelihood_derv(a, b)
+        assert (df, ddf) == (ref_df, ref_ddf)
+        assert calls[:3] == [2 + 10] * 3 and calls[-1] == 2
+        t.set_allreduce_hook(None)
+        assert lib.iqhip_bind_result_buffer(t.engine, None, 0) == 0
+    finally:
+        dist.destroy_process_group()
