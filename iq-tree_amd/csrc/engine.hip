@@ -440,6 +440,35 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         d.right_len = rlen;
         prev_dst = didx;
     }
+    // HOLD analysis (4-state kernel): a streamed left child produced by op j of this plan can stay
+    // in registers until its join k if no op in (j, k) streams, loads or parks anything itself
+    // (the usual case after heavier-first ordering: the other subtree is a short chain).
+    if (!e->mfma && !(e->ablate & 4)) {
+        std::unordered_map<const double *, int> producer;
+        for (int k = 0; k < nops; k++) {
+            DevOp &d = e->h_ops[k];
+            if (d.left_kind == CHILD_PF) {
+                auto it = producer.find(d.pf);
+                if (it != producer.end()) {
+                    const int j = it->second;
+                    bool ok = !e->h_ops[j].push_hold;
+                    for (int q = j + 1; q < k && ok; q++) {
+                        const DevOp &m = e->h_ops[q];
+                        ok = m.left_kind != CHILD_PF && m.left_kind != CHILD_HOLD && m.right_kind != CHILD_LOAD &&
+                             !m.push_hold;
+                    }
+                    if (ok) {
+                        e->h_ops[j].push_hold = 1;
+                        d.left_kind = CHILD_HOLD;
+                        d.pf = e->dummy.plh;
+                        d.pf_sc = e->dummy.sc;
+                        d.real_mask &= ~1;
+                    }
+                }
+            }
+            producer[d.dst] = k;
+        }
+    }
     for (int q = 0; q < kSentinels; q++) dummy_op(e->h_ops[nops + q]);  // targets of the look-ahead requests
     *last_dst = prev_dst;
     // LDS layout of the per-(op, child) regions, cut into chunks that fit the budget

@@ -25,7 +25,8 @@ constexpr double kLogScalingThreshold = -177.44567822334599;
 
 // LEAF: state bytes; LOAD: read now; PREV: previous op's result (registers);
 // PF: read one op ahead into the prefetch registers
-enum ChildKind : int32_t { CHILD_LEAF = 0, CHILD_LOAD = 1, CHILD_PREV = 2, CHILD_PF = 3 };
+// HOLD: parked in the HOLD registers by the producing op (push_hold) of the same launch
+enum ChildKind : int32_t { CHILD_LEAF = 0, CHILD_LOAD = 1, CHILD_PREV = 2, CHILD_PF = 3, CHILD_HOLD = 4 };
 
 // One node update as the device sees it. 16-byte aligned so that the wave-uniform reads
 // of the descriptor become scalar loads.
@@ -48,7 +49,8 @@ struct __attribute__((aligned(16))) DevOp {
     int32_t real_mask;  // bit0: pf/pf_sc are real (else dummies)
     int32_t sl_slot;    // LDS slot of the staged leaf states of the left / right child within
     int32_t sr_slot;    //   the chunk (slot 0 is shared by all non-leaf children)
-    int32_t _pad[2];
+    int32_t push_hold;  // 1: copy this op's result into the HOLD registers (consumed by a CHILD_HOLD)
+    int32_t _pad;
 };
 
 // Root branch descriptor for the lnL / theta kernels.

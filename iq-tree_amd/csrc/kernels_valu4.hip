@@ -125,7 +125,8 @@ __device__ __forceinline__ void leaf_cat4(const double *reg /* [ex B][table 5B] 
 }
 
 // One node update.  The host canonicalises every op (the Hadamard product commutes) so that
-//   left  is a LEAF or the streamed child held in the PF registers (CHILD_PF), and
+//   left  is a LEAF, the streamed child held in the PF registers (CHILD_PF) or a result parked
+//         in the HOLD registers by an earlier op of this launch      (CHILD_HOLD), and
 //   right is a LEAF or the previous result held in `prev`            (CHILD_PREV),
 // which leaves two independent wave-uniform two-way choices instead of a kind x kind product.
 // `prev` is read in place and receives the new vector.  The PF registers are consumed category
@@ -133,11 +134,12 @@ __device__ __forceinline__ void leaf_cat4(const double *reg /* [ex B][table 5B] 
 // op k+1's streamed child (nx_pf), so the prefetch needs no second register set and no copy.
 // Returns lh_max (0 for LEAF-LEAF, which the reference never rescales).
 template <int C>
-__device__ __forceinline__ double node_update4(bool leafL, bool leafR, const double *regL,
+__device__ __forceinline__ double node_update4(bool leafL, bool holdL, bool leafR, const double *regL,
                                                const double *regR, const double *s_tip,
                                                const CONST_AS double *U, const CONST_AS double *uinv,
                                                int sL, int sR, int state_unknown, const char *nx_pf,
-                                               char *dst, double (&PF)[4 * C], double (&prev)[4 * C]) {
+                                               char *dst, double (&PF)[4 * C], const double (&HOLD)[4 * C],
+                                               double (&prev)[4 * C]) {
     bool slowL = false, slowR = false;
     int rowL = 0, rowR = 0;
     if (leafL) {
@@ -156,8 +158,13 @@ __device__ __forceinline__ double node_update4(bool leafL, bool leafR, const dou
             leaf_cat4<C>(regL, s_tip, U, sL, rowL, slowL, state_unknown, c, a);
         } else {
             double l[4];
+            if (holdL) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) l[i] = regL[c * 4 + i] * PF[c * 4 + i];
+                for (int i = 0; i < 4; i++) l[i] = regL[c * 4 + i] * HOLD[c * 4 + i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) l[i] = regL[c * 4 + i] * PF[c * 4 + i];
+            }
 #pragma unroll
             for (int x = 0; x < 4; x++) {
                 double v = U[x * 4] * l[0];
@@ -267,10 +274,11 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
     const CONST_AS double *uinv = as_const(A.inv_evec);
     const CONST_AS DevOp *ops = as_const(A.ops);
 
-    double prev[B], PF[B];
+    double prev[B], PF[B], HOLD[B];
+    int hold_sc = 0;
     int pf_sc = 0, prev_sc = 0;
 #pragma unroll
-    for (int e = 0; e < B; e++) { prev[e] = 0.0; PF[e] = 0.0; }
+    for (int e = 0; e < B; e++) { prev[e] = 0.0; PF[e] = 0.0; HOLD[e] = 0.0; }
 
     // everything op k needs from memory is requested while op k-1 computes.  Prime for op 0.
     // (ops[nops] is a sentinel whose pointers are valid dummies, so the requests are unconditional)
@@ -329,12 +337,13 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
         for (int kk = 0; kk < kn; kk++, k++) {
             const CONST_AS DevOp *op = ops + k;
             const bool leafL = op->left_kind == CHILD_LEAF;
+            const bool holdL = op->left_kind == CHILD_HOLD;
             const bool leafR = op->right_kind == CHILD_LEAF;
             int sc = 0;
             // leaf states were staged into LDS when the chunk was filled
             const int sL = s_states[op->sl_slot * WG + threadIdx.x];
             const int sR = s_states[op->sr_slot * WG + threadIdx.x];
-            if (!leafL) sc += pf_sc;
+            if (!leafL) sc += holdL ? hold_sc : pf_sc;
             if (HAS_LOAD && op->right_kind == CHILD_LOAD) {
                 // both children come from memory: the left one was streamed into PF; the right
                 // one is read now into `prev`, which is dead here (it is not an input of this op)
@@ -353,8 +362,8 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
             pf_sc = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(nx->pf_sc) +
                                                        ((nreal & 1) ? soff : (uint32_t)(lane * 2)));
             char *dstp = reinterpret_cast<char *>(op->dst) + voff;
-            const double lh_max = node_update4<C>(leafL, leafR, s_reg + op->lds_left, s_reg + op->lds_right,
-                                                  s_tip, U, uinv, sL, sR, A.state_unknown, nx_pf, dstp, PF, prev);
+            const double lh_max = node_update4<C>(leafL, holdL, leafR, s_reg + op->lds_left, s_reg + op->lds_right,
+                                                  s_tip, U, uinv, sL, sR, A.state_unknown, nx_pf, dstp, PF, HOLD, prev);
             // ---- scaling (SIMD rule, phylokernel.h:379-392,461-474); TIP-TIP never scales
             const bool do_scale = !(leafL && leafR) && (lh_max < kScalingThreshold) && (invar == 0.0);
             double my_scale = 0.0;
@@ -371,6 +380,13 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
                 }
             }
             prev_sc = sc;
+            if (op->push_hold) {
+                // this result is the left child of a join a few ops ahead whose other subtree is a
+                // plain chain: park it in registers instead of re-reading 8 KiB per wave from memory
+#pragma unroll
+                for (int e = 0; e < B; e++) HOLD[e] = prev[e];
+                hold_sc = sc;
+            }
 #ifndef IQHIP_ABLATE_NOSTORE
             *reinterpret_cast<int16_t *>(reinterpret_cast<char *>(op->dst_sc) + soff) = (int16_t)sc;
 #endif
