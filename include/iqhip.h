@@ -139,6 +139,22 @@ int iqhip_derv(iqhip_engine *e, double len, double *df, double *ddf);
 /* lnL (without lh_scale_factors) from theta (phylokernel.h:1040-1122); writes _pattern_lh. */
 int iqhip_lnl_from_theta(iqhip_engine *e, double len, double *lnl);
 
+/* the whole Newton-Raphson solve of Optimization::minimizeNewton
+ * (optimization.cpp:388-450) for the branch whose theta is resident, in ONE launch: the loop
+ * "computeFuncDerv; update; test" of optimizeOneBranch (phylotree.cpp:2148-2192) runs on the device
+ * with the reference's update rule, bracketing and stopping tests (x1/x2 = min/max branch length,
+ * xacc = min branch length, max_steps = maxNRStep).  Returns the optimised length (*optx), the last
+ * second derivative (*d2l, as minimizeNewton's d2l) and the number of derivative evaluations.
+ * Not available on a sharded engine (each step would need an all-reduce): use iqhip_derv there. */
+int iqhip_newton_branch(iqhip_engine *e, double xguess, double x1, double x2, double xacc,
+                        int max_steps, double *optx, double *d2l, int *nsteps);
+/* optimizeOneBranch in one submission and one host round trip: the pending node updates of both
+ * ends of the branch (as iqhip_update_partials), theta (as iqhip_compute_theta) and the Newton
+ * solve (as iqhip_newton_branch).  nops may be 0. */
+int iqhip_optimize_branch(iqhip_engine *e, const iqhip_node_op *ops, int nops, iqhip_branch_end a,
+                          iqhip_branch_end b, double xguess, double x1, double x2, double xacc,
+                          int max_steps, double *sum_scale, double *optx, double *d2l, int *nsteps);
+
 /* Sharded / asynchronous use.  The *_async forms enqueue the same work but leave the
  * result on the device: `iqhip_result_device_ptr` is a device array of
  * iqhip_result_capacity() doubles laid out as

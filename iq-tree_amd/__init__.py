@@ -24,7 +24,7 @@ IQHIP_SYMBOLS = [
     "iqhip_set_stream", "iqhip_reserve", "iqhip_release", "iqhip_rekey", "iqhip_set_alignment",
     "iqhip_set_ptn_freq", "iqhip_set_ptn_invar", "iqhip_set_model", "iqhip_update_partials",
     "iqhip_branch_lnl", "iqhip_traverse_lnl", "iqhip_compute_theta", "iqhip_derv",
-    "iqhip_lnl_from_theta", "iqhip_bind_result_buffer", "iqhip_result_device_ptr",
+    "iqhip_lnl_from_theta", "iqhip_newton_branch", "iqhip_optimize_branch", "iqhip_bind_result_buffer", "iqhip_result_device_ptr",
     "iqhip_result_capacity", "iqhip_traverse_lnl_async", "iqhip_derv_async", "iqhip_result_read",
     "iqhip_synchronize", "iqhip_fetch_scale_num", "iqhip_fetch_pattern_lh", "iqhip_fetch_partial",
     "iqhip_fetch_theta", "iqhip_upload_partial", "iqhip_timing_enable", "iqhip_timing_read",
@@ -95,6 +95,11 @@ def libiqhip():
     lib.iqhip_compute_theta.argtypes = [vp, BranchEnd, BranchEnd]
     lib.iqhip_derv.argtypes = [vp, C.c_double, dp, dp]
     lib.iqhip_lnl_from_theta.argtypes = [vp, C.c_double, dp]
+    lib.iqhip_optimize_branch.argtypes = [vp, C.POINTER(NodeOp), C.c_int, BranchEnd, BranchEnd, C.c_double,
+                                          C.c_double, C.c_double, C.c_double, C.c_int, dp, dp, dp,
+                                          C.POINTER(C.c_int)]
+    lib.iqhip_newton_branch.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, dp, dp,
+                                        C.POINTER(C.c_int)]
     lib.iqhip_bind_result_buffer.argtypes = [vp, vp, C.c_int]
     lib.iqhip_result_device_ptr.argtypes = [vp]
     lib.iqhip_result_device_ptr.restype = vp
@@ -132,6 +137,9 @@ def libiqhost():
     lib.iqhost_attach_engine.argtypes = [vp, C.c_int]
     lib.iqhost_set_dry_run.argtypes = [vp, C.c_int]
     lib.iqhost_set_heavy_first.argtypes = [vp, C.c_int]
+    lib.iqhost_set_device_newton.argtypes = [vp, C.c_int]
+    lib.iqhost_num_derv_calls.argtypes = [vp]
+    lib.iqhost_num_derv_calls.restype = C.c_long
     lib.iqhost_engine.argtypes = [vp]
     lib.iqhost_engine.restype = vp
     lib.iqhost_set_allreduce_hook.argtypes = [vp, ALLREDUCE_HOOK, vp]
@@ -237,6 +245,13 @@ class PhyloTree:
 
     def attach_engine(self, device=0):
         self._chk(self.lib.iqhost_attach_engine(self.h, device))
+
+    def set_device_newton(self, on=True):
+        self._chk(self.lib.iqhost_set_device_newton(self.h, int(on)))
+
+    @property
+    def num_derv_calls(self):
+        return self.lib.iqhost_num_derv_calls(self.h)
 
     def set_heavy_first(self, on=True):
         self._chk(self.lib.iqhost_set_heavy_first(self.h, int(on)))

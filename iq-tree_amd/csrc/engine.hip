@@ -116,6 +116,17 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     }
     hipMemsetAsync(e->dummy.plh, 0, P * e->block * sizeof(double), e->stream);
     hipMemsetAsync(e->dummy.sc, 0, P * sizeof(int16_t), e->stream);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+            e->num_cus = cus;
+        ok = dmalloc(&e->d_newton_partials, (size_t)4 * e->num_cus) == hipSuccess &&
+             dmalloc(&e->d_newton_barrier, 1) == hipSuccess;
+        if (!ok) {
+            iqhip_destroy(e);
+            return fail(IQHIP_ERR_NOMEM, "iqhip_create: device allocation failed");
+        }
+    }
     e->d_result = e->d_result_own;
     hipMemsetAsync(e->d_theta, 0, P * e->block * sizeof(double), e->stream);
     hipMemsetAsync(e->d_pattern_lh, 0, P * sizeof(double), e->stream);
@@ -135,7 +146,8 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
     }
     void *ptrs[] = {e->d_states, e->d_freq, e->d_invar, e->d_eval, e->d_evec, e->d_inv_evec,
                     e->d_rates, e->d_props, e->d_tip, e->d_ops, e->d_val, e->d_slab,
-                    e->d_theta, e->d_pattern_lh, e->dummy.plh, e->dummy.sc};
+                    e->d_theta, e->d_pattern_lh, e->dummy.plh, e->dummy.sc, e->d_newton_partials,
+                    e->d_newton_barrier};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (e->h_ops) hipHostFree(e->h_ops);
@@ -682,6 +694,60 @@ extern "C" int iqhip_derv(iqhip_engine *e, double len, double *df, double *ddf) 
     if (isnan(a) || isinf(a)) { a = 0.0; b = 0.0; }  // phylokernel.h:647-651
     if (df) *df = a;
     if (ddf) *ddf = b;
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_newton_branch(iqhip_engine *e, double xguess, double x1, double x2, double xacc,
+                                   int max_steps, double *optx, double *d2l, int *nsteps) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    if (!e->theta_valid) return fail(IQHIP_ERR_INVALID, "iqhip_newton_branch: theta not computed");
+    if (!(x1 >= 0.0) || !(x2 > x1) || !(xacc > 0.0) || max_steps < 1 || !(xguess >= 0.0))
+        return fail(IQHIP_ERR_INVALID, "iqhip_newton_branch: bad bounds / tolerance / step count");
+    HIPCHK(launch_newton(e, xguess, x1, x2, xacc, max_steps, e->d_result));
+    rc = read_result(e, 4);
+    if (rc) return rc;
+    const int status = (int)e->h_result[3];
+    if (status == 2) return fail(IQHIP_ERR_INVALID, "Wrong computeFuncDerv (non-finite derivative)");
+    if (status == 3) return fail(IQHIP_ERR_INVALID, "Maximum number of iterations exceeded in minimizeNewton");
+    if (status == 4) return fail(IQHIP_ERR_HIP, "iqhip_newton_branch: grid barrier timed out");
+    if (optx) *optx = e->h_result[0];
+    if (d2l) *d2l = e->h_result[1];
+    if (nsteps) *nsteps = (int)e->h_result[2];
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_optimize_branch(iqhip_engine *e, const iqhip_node_op *ops, int nops, iqhip_branch_end a,
+                                     iqhip_branch_end b, double xguess, double x1, double x2, double xacc,
+                                     int max_steps, double *sum_scale, double *optx, double *d2l, int *nsteps) {
+    if (!(x1 >= 0.0) || !(x2 > x1) || !(xacc > 0.0) || max_steps < 1 || !(xguess >= 0.0))
+        return fail(IQHIP_ERR_INVALID, "iqhip_optimize_branch: bad bounds / tolerance / step count");
+    iqhip_branch_end none = {0, -1, 0};
+    int rc = IQHIP_OK;
+    if (nops > 0) rc = submit_traverse(e, ops, nops, false, none, none, 0.0);
+    else rc = check_ready(e);
+    if (rc) return rc;
+    if (nops + 6 > e->result_cap) return fail(IQHIP_ERR_INVALID, "too many node updates in one submission");
+    DevBranch br;
+    rc = build_branch(e, a, b, 0.0, -1, &br);
+    if (rc) return rc;
+    if (e->mfma) HIPCHK(launch_stream_mfma(e, 1, &br, 0.0, (int)e->ntiles));
+    else HIPCHK(launch_theta4(e, br));
+    e->theta_valid = true;
+    double *out = e->d_result + 2 + nops;
+    HIPCHK(launch_newton(e, xguess, x1, x2, xacc, max_steps, out));
+    rc = read_result(e, 2 + nops + 4);
+    if (rc) return rc;
+    if (sum_scale)
+        for (int k = 0; k < nops; k++) sum_scale[k] = e->h_result[2 + k];
+    const double *r = e->h_result + 2 + nops;
+    const int status = (int)r[3];
+    if (status == 2) return fail(IQHIP_ERR_INVALID, "Wrong computeFuncDerv (non-finite derivative)");
+    if (status == 3) return fail(IQHIP_ERR_INVALID, "Maximum number of iterations exceeded in minimizeNewton");
+    if (status == 4) return fail(IQHIP_ERR_HIP, "iqhip_optimize_branch: grid barrier timed out");
+    if (optx) *optx = r[0];
+    if (d2l) *d2l = r[1];
+    if (nsteps) *nsteps = (int)r[2];
     return IQHIP_OK;
 }
 

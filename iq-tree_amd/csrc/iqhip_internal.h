@@ -108,6 +108,9 @@ struct iqhip_engine {
     int64_t slab_cap = 0;
     double *d_theta = nullptr, *d_pattern_lh = nullptr;
     double *d_result_own = nullptr, *d_result = nullptr;
+    double *d_newton_partials = nullptr;   // [2][num_cus][2]
+    unsigned int *d_newton_barrier = nullptr;
+    int num_cus = 256;
     int result_cap = 0;
     // pinned host staging
     iqhip::DevOp *h_ops = nullptr;
@@ -136,6 +139,10 @@ hipError_t launch_theta4(iqhip_engine *e, const DevBranch &br);
 hipError_t launch_derv4(iqhip_engine *e, double len, int nwaves);
 hipError_t launch_lnl_theta4(iqhip_engine *e, double len, int nwaves);
 hipError_t launch_reduce(iqhip_engine *e, int first_row, int nrows, int nwaves);
+
+// kernels_newton.hip
+hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps,
+                         double *out);
 
 // kernels_mfma.hip (nstates 20 / 64)
 hipError_t launch_traverse_mfma(iqhip_engine *e, int nops, int nwaves);

@@ -1,0 +1,236 @@
+// kernels_newton.hip -- SURVEY.md 8(f)-1: a whole Newton-Raphson branch-length solve in ONE launch.
+//
+// The reference optimises a branch with Optimization::minimizeNewton (optimization.cpp:388-465)
+// calling PhyloTree::computeFuncDerv -> computeLikelihoodDerv (phylotree.cpp:2135-2146,
+// phylokernel.h:583-651) once per step: on a GPU that is one launch + one host round trip per
+// step (hot loop 2, latency-bound).  Here the loop itself runs on the device: every step evaluates
+// df/ddf from the resident theta_all (L2-resident after the first step), reduces them across the
+// grid in a fixed order, and every workgroup applies the reference's update rule redundantly.
+// A single workgroup needs no grid barrier at all (the common case: real alignments have a few
+// thousand patterns); larger grids use a monotonic-counter barrier (agent-scope release/acquire,
+// bounded spin) with one workgroup per CU.
+#include "iqhip_internal.h"
+
+namespace iqhip {
+
+struct NewtonArgs {
+    const double *theta;
+    const double *eval;
+    const double *rates;
+    const double *props;
+    const double *freq;
+    const double *invar;
+    double *partials;        // [2 parities][grid][2]
+    unsigned int *barrier;   // monotonic arrival counter (zeroed before the launch)
+    double *out;             // {optx, d2l, nsteps, status}
+    int64_t ntiles;          // tiles of `tile` patterns
+    int64_t nptn;
+    int n, ncat, mfma;
+    double xguess, x1, x2, xacc;
+    int max_steps;
+};
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// sum over this workgroup's patterns of f*df_ptn and f*ddf_ptn at the val arrays in LDS
+__device__ __forceinline__ void wg_partial(const NewtonArgs &A, const double *s_v0, const double *s_v1,
+                                           const double *s_v2, double *s_red, double &odf, double &oddf) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int B = A.n * A.ncat;
+    double adf = 0.0, addf = 0.0;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < A.ntiles; tile += (int64_t)gridDim.x * 4) {
+        double lh = 0.0, d1 = 0.0, d2 = 0.0;
+        int64_t ptn;
+        bool mine;
+        if (!A.mfma) {
+            ptn = tile * 64 + lane;
+            mine = ptn < A.nptn;
+            const double2 *p = reinterpret_cast<const double2 *>(A.theta + tile * (64 * B)) + lane;
+            for (int j = 0; j < B / 2; j++) {
+                const double2 t = p[j * 64];
+                lh = fma(s_v0[2 * j], t.x, lh); lh = fma(s_v0[2 * j + 1], t.y, lh);
+                d1 = fma(s_v1[2 * j], t.x, d1); d1 = fma(s_v1[2 * j + 1], t.y, d1);
+                d2 = fma(s_v2[2 * j], t.x, d2); d2 = fma(s_v2[2 * j + 1], t.y, d2);
+            }
+        } else {
+            const int p = lane & 15, g = lane >> 4;
+            ptn = tile * 16 + p;
+            mine = (g == 0) && ptn < A.nptn;
+            const double *th = A.theta + (size_t)tile * 16 * B;
+            for (int e = g; e < B; e += 4) {
+                const double t = th[(size_t)e * 16 + p];
+                lh = fma(s_v0[e], t, lh);
+                d1 = fma(s_v1[e], t, d1);
+                d2 = fma(s_v2[e], t, d2);
+            }
+            lh += __shfl_xor(lh, 16, 64); lh += __shfl_xor(lh, 32, 64);
+            d1 += __shfl_xor(d1, 16, 64); d1 += __shfl_xor(d1, 32, 64);
+            d2 += __shfl_xor(d2, 16, 64); d2 += __shfl_xor(d2, 32, 64);
+        }
+        if (mine) {
+            lh += A.invar[ptn];
+            const double f = A.freq[ptn];
+            const double inv = 1.0 / fabs(lh);
+            const double dfp = d1 * inv;
+            const double ddfp = fma(-dfp, dfp, d2 * inv);
+            adf = fma(dfp, f, adf);
+            addf = fma(ddfp, f, addf);
+        }
+    }
+    adf = wsum(adf);
+    addf = wsum(addf);
+    if (lane == 0) { s_red[2 * wave] = adf; s_red[2 * wave + 1] = addf; }
+    __syncthreads();
+    odf = (s_red[0] + s_red[2]) + (s_red[4] + s_red[6]);
+    oddf = (s_red[1] + s_red[3]) + (s_red[5] + s_red[7]);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_newton(const NewtonArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int B = A.n * A.ncat;
+    double *s_v0 = smem, *s_v1 = smem + B, *s_v2 = smem + 2 * B, *s_red = smem + 3 * B;  // s_red[8]
+    __shared__ double s_bcast[2];
+    __shared__ int s_fail;
+    if (threadIdx.x == 0) s_fail = 0;
+
+    unsigned int epoch = 0;
+    // f = -dlnL/dt, df = -d2lnL/dt2 at x (phylotree.cpp:2135-2146)
+    auto eval_at = [&](double x, double &f, double &df) {
+        for (int t = threadIdx.x; t < B; t += 256) {
+            const int c = t / A.n, i = t - c * A.n;
+            const double cof = A.eval[i] * A.rates[c];
+            const double v = exp(cof * x) * A.props[c];
+            s_v0[t] = v;
+            s_v1[t] = cof * v;
+            s_v2[t] = cof * (cof * v);
+        }
+        __syncthreads();
+        double pdf, pddf;
+        wg_partial(A, s_v0, s_v1, s_v2, s_red, pdf, pddf);
+        if (gridDim.x > 1) {
+            double *slot = A.partials + (size_t)(epoch & 1) * gridDim.x * 2;
+            if (threadIdx.x == 0) {
+                slot[2 * blockIdx.x] = pdf;
+                slot[2 * blockIdx.x + 1] = pddf;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(A.barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int target = (epoch + 1) * gridDim.x;
+                long spins = 0;
+                while (__hip_atomic_load(A.barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > 50000000L) { s_fail = 1; break; }  // never hang the GPU
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            // fixed-order sum of the workgroup partials by wave 0 (identical on every workgroup)
+            if (threadIdx.x < 64) {
+                double a = 0.0, b = 0.0;
+                for (int w = threadIdx.x; w < (int)gridDim.x; w += 64) {
+                    a += __hip_atomic_load(&slot[2 * w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    b += __hip_atomic_load(&slot[2 * w + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                a = wsum(a);
+                b = wsum(b);
+                if (threadIdx.x == 0) { s_bcast[0] = a; s_bcast[1] = b; }
+            }
+            __syncthreads();
+            pdf = s_bcast[0];
+            pddf = s_bcast[1];
+            __syncthreads();
+            epoch++;
+        }
+        if (isnan(pdf) || isinf(pdf)) { pdf = 0.0; pddf = 0.0; }  // phylokernel.h:647-651
+        f = -pdf;
+        df = -pddf;
+    };
+
+    // ---- Optimization::minimizeNewton (optimization.cpp:388-450), same control flow
+    double df, dx, f, temp, xh, xl, rts, rts_old, d2l;
+    int nsteps = 1, status = 0;
+    rts = A.xguess;
+    if (rts < A.x1) rts = A.x1;
+    if (rts > A.x2) rts = A.x2;
+    eval_at(rts, f, df);
+    d2l = df;
+    double result = rts;
+    bool done = false;
+    if (!isfinite(f) || !isfinite(df)) { status = 2; done = true; }
+    if (!done && df >= 0.0 && fabs(f) < A.xacc) done = true;
+    if (!done) {
+        if (f < 0.0) { xl = rts; xh = A.x2; } else { xh = rts; xl = A.x1; }
+        dx = fabs(xh - xl);
+        int j;
+        for (j = 1; j <= A.max_steps; j++) {
+            rts_old = rts;
+            if ((df <= 0.0) || (((rts - xh) * df - f) * ((rts - xl) * df - f) >= 0.0)) {
+                dx = 0.5 * (xh - xl);
+                rts = xl + dx;
+                d2l = df;
+                if (xl == rts) { result = rts; break; }
+            } else {
+                dx = f / df;
+                temp = rts;
+                rts -= dx;
+                d2l = df;
+                if (temp == rts) { result = rts; break; }
+            }
+            if (fabs(dx) < A.xacc || (j == A.max_steps)) { result = rts_old; break; }
+            eval_at(rts, f, df);
+            nsteps++;
+            if (!isfinite(f) || !isfinite(df)) { status = 2; result = rts_old; break; }
+            if (df > 0.0 && fabs(f) < A.xacc) { d2l = df; result = rts; break; }
+            if (f < 0.0) xl = rts; else xh = rts;
+        }
+        if (j > A.max_steps) status = 3;  // "Maximum number of iterations exceeded"
+    }
+    __syncthreads();
+    if (s_fail) status = 4;  // grid barrier timed out
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        A.out[0] = result;
+        A.out[1] = d2l;
+        A.out[2] = (double)nsteps;
+        A.out[3] = (double)status;
+    }
+}
+
+hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps,
+                         double *out) {
+    NewtonArgs A;
+    A.theta = e->d_theta;
+    A.eval = e->d_eval;
+    A.rates = e->d_rates;
+    A.props = e->d_props;
+    A.freq = e->d_freq;
+    A.invar = e->d_invar;
+    A.partials = e->d_newton_partials;
+    A.barrier = e->d_newton_barrier;
+    A.out = out;
+    A.ntiles = e->ntiles;
+    A.nptn = e->nptn;
+    A.n = e->n;
+    A.ncat = e->ncat;
+    A.mfma = e->mfma ? 1 : 0;
+    A.xguess = xguess;
+    A.x1 = x1;
+    A.x2 = x2;
+    A.xacc = xacc;
+    A.max_steps = max_steps;
+    // one workgroup per CU at most: every workgroup must be resident for the grid barrier
+    int64_t wgs = (e->ntiles + 3) / 4;
+    int grid = (int)(wgs < 1 ? 1 : (wgs > e->num_cus ? e->num_cus : wgs));
+    hipError_t s = hipMemsetAsync(e->d_newton_barrier, 0, sizeof(unsigned int), e->stream);
+    if (s != hipSuccess) return s;
+    const size_t lds = (size_t)(3 * e->block + 8) * sizeof(double);
+    hipLaunchKernelGGL(k_newton, dim3(grid), dim3(256), lds, e->stream, A);
+    return hipGetLastError();
+}
+
+}  // namespace iqhip

@@ -63,6 +63,8 @@ int iqhost_set_mem_mode(void *h, int lm) {
 }
 int iqhost_set_kernel(void *h, int lk) { IQHOST_TRY(((PhyloTree *)h)->setLikelihoodKernel((LikelihoodKernel)lk)); }
 int iqhost_attach_engine(void *h, int device) { IQHOST_TRY(((PhyloTree *)h)->attachEngine(device)); }
+int iqhost_set_device_newton(void *h, int on) { IQHOST_TRY(((PhyloTree *)h)->device_newton = on != 0); }
+long iqhost_num_derv_calls(void *h) { return ((PhyloTree *)h)->num_derv_calls; }
 int iqhost_set_heavy_first(void *h, int on) { IQHOST_TRY(((PhyloTree *)h)->heavy_first = on != 0); }
 int iqhost_set_dry_run(void *h, int on) { IQHOST_TRY(((PhyloTree *)h)->setDryRun(on != 0)); }
 void *iqhost_engine(void *h) { return ((PhyloTree *)h)->engine; }

@@ -589,6 +589,7 @@ void PhyloTree::computeLikelihoodDervHIP(PhyloNeighbor *dad_branch, PhyloNode *d
     if ((dad_branch->partial_lh_computed & 1) == 0) computePartialLikelihoodHIP(dad_branch, dad);
     if ((node_branch->partial_lh_computed & 1) == 0) computePartialLikelihoodHIP(node_branch, node);
     df = ddf = 0.0;
+    num_derv_calls++;
     if (dry_run) { theta_computed = true; return; }
     if (!engine) throw std::runtime_error("HIP likelihood kernel selected but no engine attached");
     pushInputs();
@@ -695,7 +696,34 @@ void PhyloTree::optimizeOneBranch(PhyloNode *node1, PhyloNode *node2, bool clear
     const double current_len = current_it->length;
     theta_computed = false;
     double d2l;
-    double optx = minimizeNewton(min_branch_length, current_len, max_branch_length, min_branch_length, d2l, maxNRStep);
+    double optx;
+    if (device_newton && engine && !dry_run && !allreduce_hook) {
+        // partials + theta exactly as the first computeFuncDerv of the host loop would make them
+        PhyloNeighbor *dad_branch = current_it, *node_branch = current_it_back;
+        PhyloNode *dad = current_it_back->node, *node = current_it->node;
+        if (node->isLeaf()) { std::swap(dad, node); std::swap(dad_branch, node_branch); }
+        if (!central_partial_lh) initializeAllPartialLh();
+        std::vector<PlanOp> plan;
+        if ((dad_branch->partial_lh_computed & 1) == 0) collectPlan(dad_branch, dad, plan);
+        if ((node_branch->partial_lh_computed & 1) == 0) collectPlan(node_branch, node, plan);
+        last_plan = plan;
+        pushInputs();
+        std::vector<iqhip_node_op> ops(plan.size());
+        for (size_t k = 0; k < plan.size(); k++) ops[k] = plan[k].op;
+        std::vector<double> sum_scale(plan.size() + 1, 0.0);
+        int nsteps = 0;
+        theta_computed = true;
+        check(iqhip_optimize_branch(engine, ops.empty() ? nullptr : ops.data(), (int)ops.size(),
+                                    branchEnd(node_branch), branchEnd(dad_branch), current_len, min_branch_length,
+                                    max_branch_length, min_branch_length, maxNRStep, sum_scale.data(), &optx, &d2l,
+                                    &nsteps),
+              "iqhip_optimize_branch");
+        applyScaleFactors(plan, sum_scale);
+        num_submissions++;
+        num_derv_calls += nsteps;
+    } else {
+        optx = minimizeNewton(min_branch_length, current_len, max_branch_length, min_branch_length, d2l, maxNRStep);
+    }
     if (optx > max_branch_length * 0.95) {  // newton raphson diverged, reset (phylotree.cpp:2167-2176)
         current_it->length = current_it_back->length = optx;
         double opt_lh = computeLikelihoodFromBuffer();

@@ -109,6 +109,10 @@ public:
     void attachEngine(int device);
     void setDryRun(bool on) { dry_run = on; }
     bool heavy_first = true;  // plan order of independent subtrees (see collectPlan)
+    // optimizeOneBranch: run the whole Newton-Raphson solve on the device (iqhip_newton_branch)
+    // instead of one computeLikelihoodDerv round trip per step; off -> the reference's host loop
+    bool device_newton = true;
+    long num_derv_calls = 0;  // derivative evaluations (host loop: calls; device loop: reported steps)
     iqhip_engine *engine = nullptr;
     // Pattern-sharded runs (one process per GPU): when set, every host-visible result vector
     // {lnL | df,ddf | sum_scale per op} is left on the device, handed to this hook (which

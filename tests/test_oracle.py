@@ -98,3 +98,22 @@ def test_oracle_derivatives_match_finite_differences(synth, oracle):
         np.testing.assert_allclose(ddf, (f(t + h) - 2 * f(t) + f(t - h)) / h ** 2, rtol=2e-4)
         # K9 == K6 at the current length
         assert abs(f(t) - tree.branch_lnl(a, b)[0]) <= 1e-10 * abs(f(t))
+
+
+def test_oracle_on_reference_example_alignment(synth, oracle):
+    """example/example.phy of the reference (44 taxa x 384 sites, many gaps): 355 distinct patterns as
+    SURVEY.md section 4 reports, and oracle == textbook on a random tree."""
+    import os
+    import phylip
+    import textbook
+    names, st = phylip.read_phylip_dna(os.path.join(os.path.dirname(__file__), "golden", "example.phy"))
+    assert st.shape == (44, 384)
+    pat, freq = synth.compress_patterns(st)
+    assert pat.shape[1] == 355 and freq.sum() == 384
+    model = synth.gtr_model(rates6=(1.513, 2.393, 1.769, 1.912, 2.838, 1.0), freqs=(0.249, 0.262, 0.251, 0.238),
+                            alpha=0.934, ncat=4)
+    nwk = synth.random_tree_newick(44, 12)
+    tree = oracle.OracleTree(nwk, 4, 0, pat, freq, None, model)
+    lnl, _ = tree.likelihood()
+    site = textbook.site_log_likelihoods(tree.adj, pat, model, 0, 18)
+    assert abs(lnl - float((site * freq).sum())) <= 1e-9 * abs(lnl)

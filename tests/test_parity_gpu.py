@@ -423,3 +423,75 @@ def test_rccl_allreduce_hook_single_rank(pkg, synth, oracle):
         assert lib.iqhip_bind_result_buffer(t.engine, None, 0) == 0
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------
+# Newton-Raphson branch-length solve on the device
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,ncat,seq_type,nsites", [(4, 4, 0, 150), (4, 4, 0, 6000), (20, 4, 1, 900), (64, 1, 2, 500)])
+def test_device_newton_matches_host_loop(pkg, synth, oracle, n, ncat, seq_type, nsites):
+    """iqhip_newton_branch restates minimizeNewton: it must take the same path as the host loop over
+    computeLikelihoodDerv (same number of derivative evaluations, same optimum) -- single-workgroup
+    grids (no barrier) and multi-workgroup grids (grid barrier) alike."""
+    t, ot, *_ = make_case(synth, oracle, pkg, 9, nsites, n, ncat, 500 + n + nsites, seq_type=seq_type, missing=0.02)
+    t.compute_likelihood()
+    edges = [(a, b) for a in range(t.num_nodes) for b, _ in t.neighbors(a) if a < b]
+    for (a, b) in edges[:6]:
+        start = 0.31 if (a + b) % 2 else 0.004
+        res = {}
+        for mode in (False, True):
+            t.set_device_newton(mode)
+            t.set_branch_length(a, b, start, clear_reverse=True)
+            c0 = t.num_derv_calls
+            res[mode] = (t.optimize_one_branch(a, b), t.num_derv_calls - c0)
+        (lh, ch), (ld, cd) = res[False], res[True]
+        assert abs(ld - lh) <= 1e-9 * max(lh, 1e-6), (a, b, lh, ld)
+        assert cd == ch, (a, b, ch, cd)
+        # the optimum is a stationary point of the oracle's lnL as well (or sits on a bound)
+        ot.set_length(a, b, ld)
+        odf, _ = ot.derv(a, b)
+        assert abs(odf) < 1e-3 * max(1.0, abs(ot.branch_lnl(a, b)[0])) or ld <= 1.1e-6
+
+
+def test_device_newton_optimize_all_branches(pkg, synth, oracle):
+    t, ot, *_ = make_case(synth, oracle, pkg, 16, 2500, 4, 4, 601)
+    vals = {}
+    for mode in (False, True):
+        t2, _, *_ = make_case(synth, oracle, pkg, 16, 2500, 4, 4, 601)
+        t2.set_device_newton(mode)
+        for a in range(t2.num_nodes):
+            for b, _ in t2.neighbors(a):
+                if a < b:
+                    t2.set_branch_length(a, b, 0.25, clear_reverse=False)
+        t2.clear_all_partial_lh()
+        vals[mode] = (t2.optimize_all_branches(iterations=10, tolerance=1e-4), t2.tree_string())
+    assert abs(vals[True][0] - vals[False][0]) <= 1e-9 * abs(vals[False][0])
+    ot2 = oracle.OracleTree(vals[True][1], 4, 0, ot.states, ot.freq, None, ot.model)
+    ref, _ = ot2.likelihood()
+    assert abs(vals[True][0] - ref) <= 1e-8 * abs(ref)
+
+
+def test_reference_example_alignment_with_branch_optimisation(pkg, synth, oracle):
+    """Real data (the reference's example.phy: 44 taxa, 355 patterns, many gaps): full traversal,
+    then optimizeAllBranches with the device-side Newton loop; the optimised tree's lnL is
+    re-evaluated by the oracle."""
+    import os
+    import phylip
+    names, st = phylip.read_phylip_dna(os.path.join(os.path.dirname(__file__), "golden", "example.phy"))
+    pat, freq = synth.compress_patterns(st)
+    model = synth.gtr_model(rates6=(1.513, 2.393, 1.769, 1.912, 2.838, 1.0), freqs=(0.249, 0.262, 0.251, 0.238),
+                            alpha=0.934, ncat=4)
+    nwk = synth.random_tree_newick(44, 12)
+    ot = oracle.OracleTree(nwk, 4, 0, pat, freq, None, model)
+    t = pkg.PhyloTree(nwk)
+    t.set_alignment(4, 0, pat, freq)
+    t.set_model(model)
+    t.attach_engine(0)
+    lnl = t.compute_likelihood()
+    ref, _ = ot.likelihood()
+    assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+    opt = t.optimize_all_branches(iterations=5, tolerance=1e-3)
+    assert opt > lnl
+    ot2 = oracle.OracleTree(t.tree_string(), 4, 0, pat, freq, None, model)
+    ref2, _ = ot2.likelihood()
+    assert abs(opt - ref2) <= 1e-8 * abs(ref2)
