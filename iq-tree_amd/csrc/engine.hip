@@ -98,7 +98,7 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
               dmalloc(&e->d_tip, 256 * (size_t)nstates) == hipSuccess &&
               dmalloc(&e->d_theta, P * e->block) == hipSuccess &&
               dmalloc(&e->d_pattern_lh, P) == hipSuccess;
-    e->result_cap = 2 + 4096;
+    e->result_cap = 8 + 16384;  // up to 16384 node updates per submission
     // default result buffer: pinned host memory mapped into the device address space -- the
     // reduction kernel writes the handful of result doubles straight to the host (no D2H copy
     // on the critical path); a caller-bound device buffer (RCCL) replaces it
@@ -782,12 +782,12 @@ extern "C" int iqhip_bind_result_buffer(iqhip_engine *e, void *device_ptr, int c
     HIPCHK(hipStreamSynchronize(e->stream));
     if (!device_ptr) {
         e->d_result = e->d_result_own;
-        e->result_cap = 2 + 4096;
+        e->result_cap = 8 + 16384;
         return IQHIP_OK;
     }
     if (capacity_doubles < 2) return fail(IQHIP_ERR_INVALID, "result buffer too small");
     e->d_result = (double *)device_ptr;
-    e->result_cap = std::min(capacity_doubles, 2 + 4096);
+    e->result_cap = std::min(capacity_doubles, 8 + 16384);
     return IQHIP_OK;
 }
 extern "C" void *iqhip_result_device_ptr(iqhip_engine *e) { return e ? (void *)e->d_result : nullptr; }

@@ -495,3 +495,58 @@ def test_reference_example_alignment_with_branch_optimisation(pkg, synth, oracle
     ot2 = oracle.OracleTree(t.tree_string(), 4, 0, pat, freq, None, model)
     ref2, _ = ot2.likelihood()
     assert abs(opt - ref2) <= 1e-8 * abs(ref2)
+
+
+@pytest.mark.parametrize("n,ncat,seq_type", [(4, 4, 0), (20, 4, 1)])
+def test_model_parameter_changes_between_evaluations(pkg, synth, oracle, n, ncat, seq_type):
+    """hot loop 1 as the model optimisers run it (model/modelgtr.cpp:510-518, rategamma.cpp:160-169):
+    new eigen-system / rates, clearAllPartialLH(), computeLikelihood() -- same tree, same plan
+    (whose descriptors are not re-uploaded), different numbers every time."""
+    t, ot, model, pat, freq = make_case(synth, oracle, pkg, 10, 400, n, ncat, 700 + n, seq_type=seq_type)
+    seen = set()
+    for trial, alpha in enumerate((0.9, 0.3, 2.5, 0.9)):
+        if n == 4:
+            m2 = synth.gtr_model(rates6=(1.0 + trial, 2.0, 0.7, 1.3, 3.1, 1.0), alpha=alpha, ncat=ncat)
+        else:
+            m2 = synth.random_reversible_model(n, 40 + trial, alpha=alpha, ncat=ncat)
+        t.set_model(m2)
+        t.clear_all_partial_lh()
+        lnl = t.compute_likelihood()
+        ot.set_model(m2)
+        ref, _ = ot.likelihood()
+        assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+        seen.add(round(lnl, 6))
+    assert len(seen) == 4
+
+
+def test_pattern_frequency_reweighting(pkg, synth, oracle):
+    """bootstrap-style re-weighting (iqhip_set_ptn_freq): same vectors, new pattern frequencies."""
+    t, ot, model, pat, freq = make_case(synth, oracle, pkg, 9, 600, 4, 4, 801)
+    lnl = t.compute_likelihood()
+    rng = np.random.default_rng(5)
+    f2 = rng.multinomial(int(freq.sum()), freq / freq.sum()).astype(np.float64)
+    lib = pkg.libiqhip()
+    assert lib.iqhip_set_ptn_freq(t.engine, f2.ctypes.data_as(C.POINTER(C.c_double))) == 0
+    a, b = t.current_branch()
+    v = t.compute_likelihood_branch(a, b)   # partials are frequency-independent (no scaling here)
+    ot.freq = f2
+    ot.clear()
+    ref, _ = ot.branch_lnl(a, b)
+    assert abs(v - ref) <= LNL_RTOL * abs(ref)
+    assert abs(v - lnl) > 1e-6 * abs(lnl)
+
+
+def test_many_taxa_plan_chunks_and_key_reuse(pkg, synth, oracle):
+    """600 taxa: the plan exceeds one LDS chunk several times over; afterwards every key is released
+    and the tree is evaluated again with recycled slabs."""
+    t, ot, *_ = make_case(synth, oracle, pkg, 600, 70, 4, 4, 901, lo=0.01, hi=0.05)
+    lnl = t.compute_likelihood()
+    ref, _ = ot.likelihood()
+    assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+    lib = pkg.libiqhip()
+    keys = {t.neighbor_info(a, b)["key"] for a in range(t.num_nodes) for b, _ in t.neighbors(a)} - {0}
+    assert len(keys) == 598
+    for k in keys:
+        assert lib.iqhip_release(t.engine, k) == 0
+    t.clear_all_partial_lh()
+    assert abs(t.compute_likelihood() - lnl) <= 1e-12 * abs(lnl)
