@@ -60,7 +60,7 @@ __device__ __forceinline__ void store_vec4(double *__restrict__ base, int64_t ti
 // the fused traversal kernel
 //
 // Each wave walks the whole op list for its 64 patterns, so the list is a chain of nops
-// dependent steps.  Ablation on MI355X (profiles/r01/ablation_v2.txt) showed the chain to be
+// dependent steps.  Ablation on MI355X (profiles/r01/ablation_early.txt) showed the chain to be
 // instruction-ISSUE bound, not memory bound (removing every load and store changed nothing),
 // so the body is built to issue as little as possible per step:
 //   * per-branch uniform data is reduced to the exponentials ex[c][i] = exp(eval_i r_c t)
