@@ -183,6 +183,36 @@ double PhyloTree::computeLikelihoodFromBufferHIP() {
     return current_it->lh_scale_factor + current_it_back->lh_scale_factor + lnl;  // phylokernel.h:1028
 }
 
+// Optional fast path for hot loop 2: PhyloTree::optimizeOneBranch (phylotree.cpp:2148-2192) with its
+// Newton-Raphson branch `optx = minimizeNewton(...)` replaced by ONE engine submission (pending
+// updates of both ends + theta + the whole minimizeNewton loop on the device).  Hunk in
+// optimizeOneBranch: `if (optimize_by_newton && hip_engine && computePartialLikelihoodPointer ==
+// &PhyloTree::computePartialLikelihoodHIP) optx = hipMinimizeNewton(current_len, maxNRStep); else ...`
+double PhyloTree::hipMinimizeNewton(double current_len, int maxNRStep) {
+    PhyloNeighbor *dad_branch = current_it, *node_branch = current_it_back;
+    PhyloNode *dad = (PhyloNode *)current_it_back->node, *node = (PhyloNode *)current_it->node;
+    if (node->isLeaf()) {
+        PhyloNode *tn = dad; dad = node; node = tn;
+        PhyloNeighbor *tb = dad_branch; dad_branch = node_branch; node_branch = tb;
+    }
+    if (!central_partial_lh) initializeAllPartialLh();
+    hipSync();
+    vector<iqhip_node_op> ops;
+    vector<HipPlanOp> plan;
+    if ((dad_branch->partial_lh_computed & 1) == 0) hipCollectPlan(dad_branch, dad, ops, plan);
+    if ((node_branch->partial_lh_computed & 1) == 0) hipCollectPlan(node_branch, node, ops, plan);
+    vector<double> sum_scale(ops.size() + 1);
+    double optx, d2l;
+    int nsteps;
+    theta_computed = true;
+    IQHIP_CHECK(iqhip_optimize_branch(hip_engine, ops.empty() ? NULL : &ops[0], (int)ops.size(), hipEnd(node_branch),
+                                      hipEnd(dad_branch), current_len, params->min_branch_length,
+                                      params->max_branch_length, params->min_branch_length, maxNRStep,
+                                      &sum_scale[0], &optx, &d2l, &nsteps));
+    hipApplyScale(plan, sum_scale);
+    return optx;
+}
+
 // Lazy host views for the few callers that read kernel outputs on the host
 // (computePatternLikelihood phylotree.cpp:1200-1273, computeLikelihood phylotree.cpp:1062).
 void PhyloTree::hipFetchPatternLh() {
