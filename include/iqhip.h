@@ -104,6 +104,13 @@ int iqhip_set_alignment(iqhip_engine *e, const uint8_t *states, const double *pt
 int iqhip_set_ptn_freq(iqhip_engine *e, const double *ptn_freq);   /* bootstrap re-weighting */
 int iqhip_set_ptn_invar(iqhip_engine *e, const double *ptn_invar); /* +I changed */
 
+/* +ASC (ascertainment-bias correction): the LAST n_unobserved patterns passed to
+ * iqhip_set_alignment are the unobserved constant patterns (ModelFactory::unobserved_ptns,
+ * phylokernel.h:87; frequency 0, ptn_invar = p_invar*pi) and nsites = aln->getNSite().  The lnL and
+ * derivative calls then apply phylokernel.h:868-909,968-1016 (branch), :655-725 (derivatives) and
+ * :1124-1187 (from buffer).  0 switches it off.  Not available with the *_async / Newton calls. */
+int iqhip_set_ascertainment(iqhip_engine *e, int64_t n_unobserved, double nsites);
+
 /* Model side inputs (model/modelsubst.h:248-258, model/rateheterogeneity.h:95-141,
  * phylotreesse.cpp:359-529): eval[n], evec[n*n], inv_evec[n*n], rates[ncat], props[ncat],
  * tip_partial_lh[(state_unknown+1)*n]. Invalidates nothing by itself: like the reference,

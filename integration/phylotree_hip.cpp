@@ -33,7 +33,6 @@ static inline uint64_t hipKey(PhyloNeighbor *nei) { return (uint64_t)(uintptr_t)
 bool PhyloTree::hipKernelUsable() {
     if (!aln || !model_factory || !model || !site_rate) return false;
     if (model->isMixture() || model->isSiteSpecificModel() || !model->isReversible()) return false;
-    if (model_factory->unobserved_ptns.size() > 0) return false;  // +ASC: stays on the CPU kernels
     int n = aln->num_states;
     return (n == 4 || n == 20 || n == 64) && iqhip_device_count() > 0;
 }
@@ -49,7 +48,8 @@ void PhyloTree::setLikelihoodKernelHIP() {
 // the reference recomputes its tip table (tip_partial_lh_computed == false after every
 // clearAllPartialLH(), phylotree.cpp:495-502)
 void PhyloTree::hipSync() {
-    size_t nptn = aln->size();
+    size_t norig = aln->size(), nun = model_factory->unobserved_ptns.size();
+    size_t nptn = norig + nun;  // phylokernel.h:87: the +ASC constant patterns are appended
     int ncat = site_rate->getNRate();
     if (!hip_engine || hip_nptn != nptn || hip_ncat != ncat) {
         if (hip_engine) iqhip_destroy(hip_engine);
@@ -68,8 +68,11 @@ void PhyloTree::hipSync() {
         if (!hip_aln_pushed) {
             vector<uint8_t> states((size_t)leafNum * nptn);
             for (size_t ptn = 0; ptn < nptn; ptn++)
-                for (int t = 0; t < leafNum; t++) states[(size_t)t * nptn + ptn] = (uint8_t)(*aln)[ptn][t];
+                for (int t = 0; t < leafNum; t++)
+                    states[(size_t)t * nptn + ptn] = ptn < norig ? (uint8_t)(*aln)[ptn][t]
+                                                                 : (uint8_t)model_factory->unobserved_ptns[ptn - norig];
             IQHIP_CHECK(iqhip_set_alignment(hip_engine, &states[0], ptn_freq, ptn_invar));
+            IQHIP_CHECK(iqhip_set_ascertainment(hip_engine, (int64_t)nun, (double)aln->getNSite()));
             hip_aln_pushed = true;
         } else {
             IQHIP_CHECK(iqhip_set_ptn_freq(hip_engine, ptn_freq));
@@ -187,7 +190,8 @@ double PhyloTree::computeLikelihoodFromBufferHIP() {
 // Newton-Raphson branch `optx = minimizeNewton(...)` replaced by ONE engine submission (pending
 // updates of both ends + theta + the whole minimizeNewton loop on the device).  Hunk in
 // optimizeOneBranch: `if (optimize_by_newton && hip_engine && computePartialLikelihoodPointer ==
-// &PhyloTree::computePartialLikelihoodHIP) optx = hipMinimizeNewton(current_len, maxNRStep); else ...`
+// &PhyloTree::computePartialLikelihoodHIP && model_factory->unobserved_ptns.empty())
+//     optx = hipMinimizeNewton(current_len, maxNRStep); else ...`   (+ASC keeps the host loop)
 double PhyloTree::hipMinimizeNewton(double current_len, int maxNRStep) {
     PhyloNeighbor *dad_branch = current_it, *node_branch = current_it_back;
     PhyloNode *dad = (PhyloNode *)current_it_back->node, *node = (PhyloNode *)current_it->node;

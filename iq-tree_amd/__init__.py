@@ -22,7 +22,7 @@ REPO_ROOT = os.path.dirname(_HERE)
 IQHIP_SYMBOLS = [
     "iqhip_last_error", "iqhip_abi_version", "iqhip_device_count", "iqhip_create", "iqhip_destroy",
     "iqhip_set_stream", "iqhip_reserve", "iqhip_release", "iqhip_rekey", "iqhip_set_alignment",
-    "iqhip_set_ptn_freq", "iqhip_set_ptn_invar", "iqhip_set_model", "iqhip_update_partials",
+    "iqhip_set_ptn_freq", "iqhip_set_ptn_invar", "iqhip_set_ascertainment", "iqhip_set_model", "iqhip_update_partials",
     "iqhip_branch_lnl", "iqhip_traverse_lnl", "iqhip_compute_theta", "iqhip_derv",
     "iqhip_lnl_from_theta", "iqhip_newton_branch", "iqhip_optimize_branch", "iqhip_bind_result_buffer", "iqhip_result_device_ptr",
     "iqhip_result_capacity", "iqhip_traverse_lnl_async", "iqhip_derv_async", "iqhip_result_read",
@@ -87,6 +87,7 @@ def libiqhip():
     lib.iqhip_set_alignment.argtypes = [vp, C.POINTER(C.c_uint8), dp, dp]
     lib.iqhip_set_ptn_freq.argtypes = [vp, dp]
     lib.iqhip_set_ptn_invar.argtypes = [vp, dp]
+    lib.iqhip_set_ascertainment.argtypes = [vp, C.c_int64, C.c_double]
     lib.iqhip_set_model.argtypes = [vp, dp, dp, dp, dp, dp, C.c_int, dp]
     lib.iqhip_update_partials.argtypes = [vp, C.POINTER(NodeOp), C.c_int, dp]
     lib.iqhip_branch_lnl.argtypes = [vp, BranchEnd, BranchEnd, C.c_double, dp]
@@ -131,6 +132,7 @@ def libiqhost():
     lib.iqhost_destroy.argtypes = [vp]
     lib.iqhost_destroy.restype = None
     lib.iqhost_set_alignment.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_uint8), dp, dp]
+    lib.iqhost_set_ascertainment.argtypes = [vp, C.c_int64, C.c_double]
     lib.iqhost_set_model.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp]
     lib.iqhost_set_mem_mode.argtypes = [vp, C.c_int]
     lib.iqhost_set_kernel.argtypes = [vp, C.c_int]
@@ -228,6 +230,10 @@ class PhyloTree:
         self._chk(self.lib.iqhost_set_alignment(self.h, nstates, seq_type, self.nptn,
                                                 states.ctypes.data_as(C.POINTER(C.c_uint8)),
                                                 _dptr(f), _dptr(iv)))
+
+    def set_ascertainment(self, n_unobserved, nsites):
+        """+ASC: the last n_unobserved patterns of set_alignment are the unobserved constant patterns."""
+        self._chk(self.lib.iqhost_set_ascertainment(self.h, int(n_unobserved), float(nsites)))
 
     def set_model(self, model):
         """model: object with eval, evec, inv_evec, rates, props (see synth.Model)."""

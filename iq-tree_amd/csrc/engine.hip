@@ -297,6 +297,16 @@ extern "C" int iqhip_set_alignment(iqhip_engine *e, const uint8_t *states, const
     return IQHIP_OK;
 }
 
+extern "C" int iqhip_set_ascertainment(iqhip_engine *e, int64_t n_unobserved, double nsites) {
+    if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    if (n_unobserved < 0 || n_unobserved >= e->nptn || (n_unobserved > 0 && !(nsites > 0.0)))
+        return fail(IQHIP_ERR_INVALID, "iqhip_set_ascertainment: bad pattern count / site count");
+    e->n_unobs = n_unobserved;
+    e->asc_nsites = nsites;
+    e->pattern_lh_shift = 0.0;
+    return IQHIP_OK;
+}
+
 extern "C" int iqhip_set_model(iqhip_engine *e, const double *eval, const double *evec,
                                const double *inv_evec, const double *rates, const double *props,
                                int state_unknown, const double *tip_partial_lh) {
@@ -541,11 +551,10 @@ static int build_branch(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b,
     if (a.leaf >= 0 && b.leaf >= 0)
         return fail(IQHIP_ERR_INVALID, "branch with two leaf ends (2-taxon tree) is not supported");
     if (b.leaf >= 0) std::swap(a, b);  // the reference puts the leaf on the `dad` side (:739-746)
-    const int16_t *sc_unused;
     const uint8_t *st_unused;
-    int rc = resolve_child(e, a.key, a.leaf, prev_dst, &br->a, &sc_unused, &br->a_states, &br->a_kind);
+    int rc = resolve_child(e, a.key, a.leaf, prev_dst, &br->a, &br->a_sc, &br->a_states, &br->a_kind);
     if (rc) return rc;
-    rc = resolve_child(e, b.key, b.leaf, prev_dst, &br->b, &sc_unused, &st_unused, &br->b_kind);
+    rc = resolve_child(e, b.key, b.leaf, prev_dst, &br->b, &br->b_sc, &st_unused, &br->b_kind);
     if (rc) return rc;
     br->len = len;
     return IQHIP_OK;
@@ -619,6 +628,20 @@ static int repair_lnl(iqhip_engine *e, double *lnl) {
     return IQHIP_OK;
 }
 
+// +ASC finalisation of a lnL evaluation (phylokernel.h:1009-1016, 1183-1186): result[1] holds
+// prob_const; tree_lh -= nsites*log(1-prob_const), _pattern_lh[observed] -= log(1-prob_const)
+static int asc_finish_lnl(iqhip_engine *e, double *lnl) {
+    e->pattern_lh_shift = 0.0;
+    if (e->n_unobs == 0) return IQHIP_OK;
+    const double pc = e->h_result[1];
+    if (!(pc < 1.0 && pc >= 0.0))
+        return fail(IQHIP_ERR_INVALID, "+ASC: prob_const outside [0,1) (the reference asserts here)");
+    const double lp = log(1.0 - pc);
+    e->pattern_lh_shift = lp;
+    *lnl -= e->asc_nsites * lp;
+    return IQHIP_OK;
+}
+
 extern "C" int iqhip_update_partials(iqhip_engine *e, const iqhip_node_op *ops, int nops,
                                      double *sum_scale) {
     iqhip_branch_end none = {0, -1, 0};
@@ -645,6 +668,8 @@ extern "C" int iqhip_traverse_lnl(iqhip_engine *e, const iqhip_node_op *ops, int
         rc = repair_lnl(e, &v);
         if (rc) return rc;
     }
+    rc = asc_finish_lnl(e, &v);
+    if (rc) return rc;
     if (lnl) *lnl = v;
     return IQHIP_OK;
 }
@@ -656,6 +681,8 @@ extern "C" int iqhip_branch_lnl(iqhip_engine *e, iqhip_branch_end a, iqhip_branc
 
 extern "C" int iqhip_traverse_lnl_async(iqhip_engine *e, const iqhip_node_op *ops, int nops,
                                         iqhip_branch_end a, iqhip_branch_end b, double len) {
+    if (e && e->n_unobs > 0)
+        return fail(IQHIP_ERR_UNSUPPORTED, "+ASC needs the synchronous calls (its correction is applied on the host)");
     return submit_traverse(e, ops, nops, true, a, b, len);
 }
 
@@ -668,6 +695,8 @@ extern "C" int iqhip_compute_theta(iqhip_engine *e, iqhip_branch_end a, iqhip_br
     if (e->mfma) HIPCHK(launch_stream_mfma(e, 1, &br, 0.0, (int)e->ntiles));
     else HIPCHK(launch_theta4(e, br));
     e->theta_valid = true;
+    e->theta_a_sc = br.a_sc;
+    e->theta_b_sc = br.b_sc;
     return IQHIP_OK;
 }
 
@@ -676,22 +705,29 @@ extern "C" int iqhip_derv_async(iqhip_engine *e, double len) {
     if (rc) return rc;
     if (!e->theta_valid) return fail(IQHIP_ERR_INVALID, "iqhip_derv: theta not computed");
     if (!(len >= 0.0)) return fail(IQHIP_ERR_INVALID, "negative or NaN branch length");
-    rc = ensure_slab_rows(e, 2);
+    const int nrows = e->n_unobs > 0 ? 5 : 2;  // +ASC: prob_const, df_const, ddf_const as well
+    rc = ensure_slab_rows(e, nrows);
     if (rc) return rc;
     const int nwaves = (int)e->ntiles;
     if (e->mfma) HIPCHK(launch_stream_mfma(e, 2, nullptr, len, nwaves));
     else HIPCHK(launch_derv4(e, len, nwaves));
-    HIPCHK(launch_reduce(e, 0, 2, nwaves));
+    HIPCHK(launch_reduce(e, 0, nrows, nwaves));
     return IQHIP_OK;
 }
 
 extern "C" int iqhip_derv(iqhip_engine *e, double len, double *df, double *ddf) {
     int rc = iqhip_derv_async(e, len);
     if (rc) return rc;
-    rc = read_result(e, 2);
+    rc = read_result(e, e->n_unobs > 0 ? 5 : 2);
     if (rc) return rc;
     double a = e->h_result[0], b = e->h_result[1];
     if (isnan(a) || isinf(a)) { a = 0.0; b = 0.0; }  // phylokernel.h:647-651
+    if (e->n_unobs > 0) {  // phylokernel.h:719-724
+        const double prob_const = 1.0 - e->h_result[2];
+        const double df_frac = e->h_result[3] / prob_const, ddf_frac = e->h_result[4] / prob_const;
+        a += e->asc_nsites * df_frac;
+        b += e->asc_nsites * (ddf_frac + df_frac * df_frac);
+    }
     if (df) *df = a;
     if (ddf) *ddf = b;
     return IQHIP_OK;
@@ -702,6 +738,7 @@ extern "C" int iqhip_newton_branch(iqhip_engine *e, double xguess, double x1, do
     int rc = check_ready(e);
     if (rc) return rc;
     if (!e->theta_valid) return fail(IQHIP_ERR_INVALID, "iqhip_newton_branch: theta not computed");
+    if (e->n_unobs > 0) return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_newton_branch: +ASC uses iqhip_derv");
     if (!(x1 >= 0.0) || !(x2 > x1) || !(xacc > 0.0) || max_steps < 1 || !(xguess >= 0.0))
         return fail(IQHIP_ERR_INVALID, "iqhip_newton_branch: bad bounds / tolerance / step count");
     HIPCHK(launch_newton(e, xguess, x1, x2, xacc, max_steps, e->d_result));
@@ -722,6 +759,7 @@ extern "C" int iqhip_optimize_branch(iqhip_engine *e, const iqhip_node_op *ops, 
                                      int max_steps, double *sum_scale, double *optx, double *d2l, int *nsteps) {
     if (!(x1 >= 0.0) || !(x2 > x1) || !(xacc > 0.0) || max_steps < 1 || !(xguess >= 0.0))
         return fail(IQHIP_ERR_INVALID, "iqhip_optimize_branch: bad bounds / tolerance / step count");
+    if (e && e->n_unobs > 0) return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_optimize_branch: +ASC uses iqhip_derv");
     iqhip_branch_end none = {0, -1, 0};
     int rc = IQHIP_OK;
     if (nops > 0) rc = submit_traverse(e, ops, nops, false, none, none, 0.0);
@@ -734,6 +772,8 @@ extern "C" int iqhip_optimize_branch(iqhip_engine *e, const iqhip_node_op *ops, 
     if (e->mfma) HIPCHK(launch_stream_mfma(e, 1, &br, 0.0, (int)e->ntiles));
     else HIPCHK(launch_theta4(e, br));
     e->theta_valid = true;
+    e->theta_a_sc = br.a_sc;
+    e->theta_b_sc = br.b_sc;
     double *out = e->d_result + 2 + nops;
     HIPCHK(launch_newton(e, xguess, x1, x2, xacc, max_steps, out));
     rc = read_result(e, 2 + nops + 4);
@@ -761,14 +801,16 @@ extern "C" int iqhip_lnl_from_theta(iqhip_engine *e, double len, double *lnl) {
     const int nwaves = (int)e->ntiles;
     if (e->mfma) HIPCHK(launch_stream_mfma(e, 3, nullptr, len, nwaves));
     else HIPCHK(launch_lnl_theta4(e, len, nwaves));
-    HIPCHK(launch_reduce(e, 0, 1, nwaves));
-    rc = read_result(e, 1);
+    HIPCHK(launch_reduce(e, 0, 2, nwaves));
+    rc = read_result(e, 2);
     if (rc) return rc;
     double v = e->h_result[0];
     if (isnan(v) || isinf(v)) {
         rc = repair_lnl(e, &v);
         if (rc) return rc;
     }
+    rc = asc_finish_lnl(e, &v);
+    if (rc) return rc;
     if (lnl) *lnl = v;
     return IQHIP_OK;
 }
@@ -861,6 +903,11 @@ extern "C" int iqhip_fetch_pattern_lh(iqhip_engine *e, double *out) {
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(out, e->d_pattern_lh, sizeof(double) * (size_t)e->nptn, hipMemcpyDeviceToHost));
+    if (e->n_unobs > 0) {  // phylokernel.h:1013-1014: observed patterns only
+        const int64_t nobs = e->nptn - e->n_unobs;
+        for (int64_t p = 0; p < nobs; p++) out[p] -= e->pattern_lh_shift;
+        for (int64_t p = nobs; p < e->nptn; p++) out[p] = 0.0;
+    }
     return IQHIP_OK;
 }
 

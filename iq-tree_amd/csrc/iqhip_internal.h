@@ -58,6 +58,8 @@ struct __attribute__((aligned(16))) DevBranch {
     const double *a;            // internal side A (nullptr when A is a leaf)
     const uint8_t *a_states;    // leaf side states (nullptr when A is internal)
     const double *b;            // always internal
+    const int16_t *a_sc;        // scale counters of the internal ends (+ASC rescale rule), else nullptr
+    const int16_t *b_sc;
     int32_t a_kind;             // CHILD_LEAF / CHILD_LOAD / CHILD_PREV
     int32_t b_kind;             // CHILD_LOAD / CHILD_PREV
     double len;
@@ -89,6 +91,13 @@ struct iqhip_engine {
     int block = 0;         // n*ncat
     int state_unknown = -1;
     bool model_set = false, aln_set = false, theta_valid = false;
+    // +ASC (phylokernel.h:868-909,655-725,1124-1187): the last n_unobs patterns are the unobserved
+    // constant patterns; asc_nsites = aln->getNSite()
+    int64_t n_unobs = 0;
+    double asc_nsites = 0.0;
+    double pattern_lh_shift = 0.0;        // log(1 - prob_const) of the last lnL evaluation
+    const int16_t *theta_a_sc = nullptr;  // scale counters of the ends theta was built from
+    const int16_t *theta_b_sc = nullptr;
 
     hipStream_t stream = nullptr;
     bool own_stream = false;

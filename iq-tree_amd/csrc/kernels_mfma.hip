@@ -493,6 +493,9 @@ struct StreamMArgs {
     double *slab;
     int64_t ntiles;
     int64_t nptn;
+    int64_t nobs;             // [nobs, nptn): +ASC unobserved constant patterns
+    const int16_t *a_sc;      // scale counters of the branch ends (lnL modes, +ASC rescale rule)
+    const int16_t *b_sc;
     int nwaves;
     int n;
     int ncat;
@@ -554,11 +557,15 @@ __global__ __launch_bounds__(256) void k_stream_mfma(const StreamMArgs A) {
         d2 += __shfl_xor(d2, 16, 64);
         d2 += __shfl_xor(d2, 32, 64);
     }
-    lh += A.invar[ptn];
-    const double f = in ? A.freq[ptn] : 0.0;
-    const bool mine = (g == 0) && in;
+    const double iv = A.invar[ptn];
+    const bool obs = ptn < A.nobs;
+    const bool unobs = (g == 0) && ptn >= A.nobs && in;
+    const double f = obs ? A.freq[ptn] : 0.0;
+    const bool mine = (g == 0) && obs;
+    const bool asc = A.nobs < A.nptn;
     if (MODE == 2) {
-        const double inv = 1.0 / fabs(lh);
+        const double lhi = lh + iv;
+        const double inv = 1.0 / fabs(lhi);
         const double dfp = d1 * inv;
         const double ddfp = fma(-dfp, dfp, d2 * inv);
         const double wa = wave_sum_m(mine ? dfp * f : 0.0), wb = wave_sum_m(mine ? ddfp * f : 0.0);
@@ -566,20 +573,37 @@ __global__ __launch_bounds__(256) void k_stream_mfma(const StreamMArgs A) {
             A.slab[tile] = wa;
             A.slab[(size_t)A.nwaves + tile] = wb;
         }
+        if (asc) {  // phylokernel.h:655-725
+            const double w2 = wave_sum_m(unobs ? lhi : 0.0), w3 = wave_sum_m(unobs ? d1 : 0.0),
+                         w4 = wave_sum_m(unobs ? d2 : 0.0);
+            if (lane == 0) {
+                A.slab[(size_t)2 * A.nwaves + tile] = w2;
+                A.slab[(size_t)3 * A.nwaves + tile] = w3;
+                A.slab[(size_t)4 * A.nwaves + tile] = w4;
+            }
+        }
     } else {
-        const double plh = log(fabs(lh));
+        double pc = 0.0;
+        if (asc && unobs) {  // phylokernel.h:894-900, 989-995, 1157-1163
+            int ssc = 0;
+            if (A.a_sc) ssc += A.a_sc[ptn];
+            if (A.b_sc) ssc += A.b_sc[ptn];
+            pc = (ssc >= 1 ? lh * kScalingThreshold : lh) + iv;
+        }
+        const double plh = log(fabs(lh + iv));
         if (g == 0) A.pattern_lh[ptn] = plh;
         const double wa = wave_sum_m(mine ? plh * f : 0.0);
+        const double wpc = asc ? wave_sum_m(pc) : 0.0;
         if (lane == 0) {
             A.slab[tile] = wa;
-            A.slab[(size_t)A.nwaves + tile] = 0.0;
+            A.slab[(size_t)A.nwaves + tile] = wpc;
         }
     }
 }
 
 hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, double len, int nwaves) {
     StreamMArgs A;
-    if (br) A.br = *br; else A.br = DevBranch{nullptr, nullptr, nullptr, 0, 0, 0.0};
+    if (br) A.br = *br; else A.br = DevBranch{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.0};
     A.tip = e->d_tip;
     A.eval = e->d_eval;
     A.rates = e->d_rates;
@@ -591,6 +615,9 @@ hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, do
     A.slab = e->d_slab;
     A.ntiles = e->ntiles;
     A.nptn = e->nptn;
+    A.nobs = e->nptn - e->n_unobs;
+    A.a_sc = (mode == 0) ? (br ? br->a_sc : nullptr) : e->theta_a_sc;
+    A.b_sc = (mode == 0) ? (br ? br->b_sc : nullptr) : e->theta_b_sc;
     A.nwaves = nwaves;
     A.n = e->n;
     A.ncat = e->ncat;

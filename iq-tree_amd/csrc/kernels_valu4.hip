@@ -90,6 +90,7 @@ struct Trav4Args {
     double *slab;      // [nvals][nwaves] wave partials
     int64_t ntiles;
     int64_t nptn;
+    int64_t nobs;      // observed patterns; [nobs, nptn) are the +ASC unobserved constant patterns
     int nops;
     int nwaves;
     int state_unknown;
@@ -424,14 +425,26 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
 #pragma unroll
             for (int e = 0; e < B; e++) lh = fma(s_val[e] * Av[e], Bv[e], lh);
         }
+        double pc = 0.0;
+        if (A.nobs < A.nptn) {
+            // +ASC: prob_const = sum over the unobserved constant patterns of lh_ptn, the block sum
+            // multiplied by 2^-256 once when the summed scale counters are >= 1 (phylokernel.h:894-897,
+            // :989-992), then + ptn_invar
+            if (ptn >= A.nobs && ptn < A.nptn) {
+                int ssc = (A.root.b_kind == CHILD_PREV) ? prev_sc : (int)A.root.b_sc[ptn];
+                if (A.root.a_kind != CHILD_LEAF) ssc += (A.root.a_kind == CHILD_PREV) ? prev_sc : (int)A.root.a_sc[ptn];
+                pc = (ssc >= 1 ? lh * kScalingThreshold : lh) + invar;
+            }
+        }
         lh += invar;
         const double plh = log(fabs(lh));
         A.pattern_lh[ptn] = plh;
-        const double acc = (ptn < A.nptn) ? plh * freq : 0.0;
+        const double acc = (ptn < A.nobs) ? plh * freq : 0.0;
         const double ws = wave_sum(acc);
+        const double wpc = (A.nobs < A.nptn) ? wave_sum(pc) : 0.0;
         if (lane == 0) {
             A.slab[gw] = ws;
-            A.slab[(size_t)A.nwaves + gw] = 0.0;
+            A.slab[(size_t)A.nwaves + gw] = wpc;
         }
     }
 }
@@ -482,12 +495,13 @@ hipError_t launch_traverse4(iqhip_engine *e, int nops, const DevBranch *root, in
     A.slab = e->d_slab;
     A.ntiles = e->ntiles;
     A.nptn = e->nptn;
+    A.nobs = e->nptn - e->n_unobs;
     A.nops = nops;
     A.nwaves = nwaves;
     A.state_unknown = e->state_unknown;
     A.has_root = root ? 1 : 0;
     A.lds_reg_doubles = e->plan_lds_doubles;
-    if (root) A.root = *root; else A.root = DevBranch{nullptr, nullptr, nullptr, 0, 0, 0.0};
+    if (root) A.root = *root; else A.root = DevBranch{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.0};
     switch (e->ncat) {
         case 1: return launch_trav_wg<1>(e, A);
         case 2: return launch_trav_wg<2>(e, A);
@@ -555,7 +569,7 @@ __global__ __launch_bounds__(256) void k_theta_reduce4(
     const double *__restrict__ rates, const double *__restrict__ props, double len,
     const double *__restrict__ freq, const double *__restrict__ invar,
     double *__restrict__ pattern_lh, double *__restrict__ slab, int64_t ntiles, int64_t nptn,
-    int nwaves) {
+    int nwaves, int64_t nobs, const int16_t *__restrict__ a_sc, const int16_t *__restrict__ b_sc) {
     constexpr int B = 4 * C;
     __shared__ double s_v0[B], s_v1[B], s_v2[B];
     if (threadIdx.x < B) {
@@ -574,7 +588,8 @@ __global__ __launch_bounds__(256) void k_theta_reduce4(
     const int64_t ptn = tile * 64 + lane;
     double Th[B];
     load_vec4<C>(theta, tile, lane, Th);
-    const double f = (ptn < nptn) ? freq[ptn] : 0.0;
+    const double f = (ptn < nobs) ? freq[ptn] : 0.0;
+    const bool unobs = ptn >= nobs && ptn < nptn;  // +ASC tail
     double lh = 0.0, d1 = 0.0, d2 = 0.0;
 #pragma unroll
     for (int e = 0; e < B; e++) {
@@ -584,24 +599,45 @@ __global__ __launch_bounds__(256) void k_theta_reduce4(
             d2 = fma(s_v2[e], Th[e], d2);
         }
     }
-    lh += invar[ptn];
+    const double iv = invar[ptn];
     if (MODE == 0) {
-        const double inv = 1.0 / fabs(lh);
+        const double lhi = lh + iv;
+        const double inv = 1.0 / fabs(lhi);
         const double dfp = d1 * inv;
         const double ddfp = fma(-dfp, dfp, d2 * inv);
-        const double a = (ptn < nptn) ? dfp * f : 0.0;
-        const double b = (ptn < nptn) ? ddfp * f : 0.0;
+        const double a = (ptn < nobs) ? dfp * f : 0.0;
+        const double b = (ptn < nobs) ? ddfp * f : 0.0;
         const double wa = wave_sum(a), wb = wave_sum(b);
         if (lane == 0) {
             slab[gw] = wa;
             slab[(size_t)nwaves + gw] = wb;
         }
+        if (nobs < nptn) {  // phylokernel.h:655-725: plain sums over the unobserved patterns, no rescale
+            const double w2 = wave_sum(unobs ? lhi : 0.0), w3 = wave_sum(unobs ? d1 : 0.0),
+                         w4 = wave_sum(unobs ? d2 : 0.0);
+            if (lane == 0) {
+                slab[(size_t)2 * nwaves + gw] = w2;
+                slab[(size_t)3 * nwaves + gw] = w3;
+                slab[(size_t)4 * nwaves + gw] = w4;
+            }
+        }
     } else {
-        const double plh = log(fabs(lh));
+        double pc = 0.0;
+        if (nobs < nptn && unobs) {  // phylokernel.h:1138-1163
+            int ssc = 0;
+            if (a_sc) ssc += a_sc[ptn];
+            if (b_sc) ssc += b_sc[ptn];
+            pc = (ssc >= 1 ? lh * kScalingThreshold : lh) + iv;
+        }
+        const double plh = log(fabs(lh + iv));
         pattern_lh[ptn] = plh;
-        const double a = (ptn < nptn) ? plh * f : 0.0;
+        const double a = (ptn < nobs) ? plh * f : 0.0;
         const double wa = wave_sum(a);
-        if (lane == 0) slab[gw] = wa;
+        const double wpc = (nobs < nptn) ? wave_sum(pc) : 0.0;
+        if (lane == 0) {
+            slab[gw] = wa;
+            slab[(size_t)nwaves + gw] = wpc;
+        }
     }
 }
 
@@ -612,7 +648,8 @@ static hipError_t launch_theta_reduce(iqhip_engine *e, double len, int nwaves) {
     case Cv:                                                                                   \
         hipLaunchKernelGGL((k_theta_reduce4<Cv, MODE>), dim3(grid), dim3(256), 0, e->stream,   \
                            e->d_theta, e->d_eval, e->d_rates, e->d_props, len, e->d_freq,      \
-                           e->d_invar, e->d_pattern_lh, e->d_slab, e->ntiles, e->nptn, nwaves); \
+                           e->d_invar, e->d_pattern_lh, e->d_slab, e->ntiles, e->nptn, nwaves,  \
+                           e->nptn - e->n_unobs, e->theta_a_sc, e->theta_b_sc);                \
         break;
     switch (e->ncat) {
         IQ_TR(1) IQ_TR(2) IQ_TR(3) IQ_TR(4) IQ_TR(5) IQ_TR(6) IQ_TR(8)

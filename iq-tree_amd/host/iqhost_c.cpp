@@ -54,6 +54,9 @@ int iqhost_set_alignment(void *h, int nstates, int seq_type, int64_t nptn, const
                          const double *freq, const double *invar) {
     IQHOST_TRY(((PhyloTree *)h)->setAlignment(nstates, (SeqType)seq_type, nptn, states, freq, invar));
 }
+int iqhost_set_ascertainment(void *h, int64_t n_unobserved, double nsites) {
+    IQHOST_TRY(((PhyloTree *)h)->setAscertainment(n_unobserved, nsites));
+}
 int iqhost_set_model(void *h, int ncat, const double *eval, const double *evec, const double *inv_evec,
                      const double *rates, const double *props) {
     IQHOST_TRY(((PhyloTree *)h)->setModel(ncat, eval, evec, inv_evec, rates, props));

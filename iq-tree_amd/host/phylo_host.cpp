@@ -266,6 +266,13 @@ void PhyloTree::setAlignment(int nstates, SeqType st, int64_t nptn_, const uint8
     inputs_dirty = true;
 }
 
+void PhyloTree::setAscertainment(int64_t n_unobs, double nsites) {
+    if (n_unobs < 0 || n_unobs >= nptn) throw std::runtime_error("setAscertainment: bad pattern count");
+    n_unobserved = n_unobs;
+    asc_nsites = nsites;
+    inputs_dirty = true;
+}
+
 void PhyloTree::setModel(int ncat_, const double *eval, const double *evec, const double *inv_evec,
                          const double *rates, const double *props) {
     if (num_states <= 0) throw std::runtime_error("setAlignment first");
@@ -337,6 +344,7 @@ void PhyloTree::pushInputs() {
           "iqhip_set_model");
     check(iqhip_set_alignment(engine, aln_states.data(), ptn_freq.data(), ptn_invar.data()),
           "iqhip_set_alignment");
+    check(iqhip_set_ascertainment(engine, n_unobserved, asc_nsites), "iqhip_set_ascertainment");
     inputs_dirty = false;
 }
 
@@ -637,7 +645,7 @@ double PhyloTree::computeLikelihood(double *pattern_lh) {
         if (current_it->lh_scale_factor < 0.0) {  // phylotree.cpp:1059-1069
             std::vector<UBYTE> sc((size_t)nptn);
             fetchScaleNum(current_it, sc.data());
-            for (int64_t i = 0; i < nptn; i++)
+            for (int64_t i = 0; i < nptn - n_unobserved; i++)
                 pattern_lh[i] += std::max(sc[i], UBYTE(0)) * LOG_SCALING_THRESHOLD;
         }
     }
@@ -697,7 +705,7 @@ void PhyloTree::optimizeOneBranch(PhyloNode *node1, PhyloNode *node2, bool clear
     theta_computed = false;
     double d2l;
     double optx;
-    if (device_newton && engine && !dry_run && !allreduce_hook) {
+    if (device_newton && engine && !dry_run && !allreduce_hook && n_unobserved == 0) {
         // partials + theta exactly as the first computeFuncDerv of the host loop would make them
         PhyloNeighbor *dad_branch = current_it, *node_branch = current_it_back;
         PhyloNode *dad = current_it_back->node, *node = current_it->node;

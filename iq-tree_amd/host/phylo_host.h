@@ -93,6 +93,11 @@ public:
     // ---- data + model (the kernel's inputs, SURVEY 8a a5,a6,a13) -------------------------
     void setAlignment(int nstates, SeqType seq_type, int64_t nptn, const uint8_t *states /*[leaf][ptn]*/,
                       const double *ptn_freq, const double *ptn_invar);
+    // +ASC (ModelFactory::unobserved_ptns, model/modelfactory.cpp:359-370): the last n_unobserved
+    // patterns of setAlignment are the unobserved constant patterns; nsites = aln->getNSite()
+    void setAscertainment(int64_t n_unobserved, double nsites);
+    int64_t n_unobserved = 0;
+    double asc_nsites = 0.0;
     void setModel(int ncat, const double *eval, const double *evec, const double *inv_evec,
                   const double *rates, const double *props);
     int num_states = 0, ncat = 0, STATE_UNKNOWN = 0;

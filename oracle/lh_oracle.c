@@ -349,3 +349,85 @@ double oracle_lnl_from_theta(int n, int ncat, size_t nptn, const double *eval,
     free(val);
     return tree_lh;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Ascertainment-bias correction (+ASC): the unobserved constant patterns are the trailing
+ * `n_unobs` patterns of every array (phylokernel.h:87,100: nptn = aln->size() + unobserved_ptns).
+ * The callers above are run on the observed prefix only; these two functions restate what the
+ * reference does with the tail.
+ * ------------------------------------------------------------------------------------------- */
+
+/* prob_const of computeLikelihoodBranchEigenSIMD, phylokernel.h:868-909 (leaf form) and :968-1005
+ * (internal form): sum over the unobserved patterns of lh_ptn, where the block sum is multiplied
+ * by 2^-256 ONCE when the summed scale counters are >= 1 (the 2016-01-21 bugfix, :894-897,:989-992),
+ * then ptn_invar is added.  All pointers address the first unobserved pattern. */
+double oracle_asc_prob_const_branch(int n, int ncat, size_t n_unobs, const double *eval,
+                                    const double *rates, const double *props, double len,
+                                    const double *tip, const uint8_t *dad_states, const double *dad_plh,
+                                    const short *dad_scale, const double *node_plh,
+                                    const short *node_scale, const double *ptn_invar) {
+    size_t block = (size_t)n * ncat;
+    double *val = (double *)malloc(sizeof(double) * block);
+    branch_val(n, ncat, eval, rates, props, len, val);
+    double prob_const = 0.0;
+    for (size_t ptn = 0; ptn < n_unobs; ptn++) {
+        const double *b = node_plh + ptn * block;
+        double l[4];
+        int sc = node_scale[ptn];
+        if (dad_states) {
+            const double *t = tip + (size_t)dad_states[ptn] * n;
+            for (int k = 0; k < 4; k++) l[k] = (val[k] * t[k % n]) * b[k];
+            for (size_t i = 4; i < block; i += 4)
+                for (int k = 0; k < 4; k++) l[k] = (val[i + k] * t[(i + k) % n]) * b[i + k] + l[k];
+        } else {
+            const double *a = dad_plh + ptn * block;
+            sc += dad_scale[ptn];
+            for (int k = 0; k < 4; k++) l[k] = 0.0;
+            for (size_t i = 0; i < block; i += 4)
+                for (int k = 0; k < 4; k++) l[k] = (val[i + k] * b[i + k]) * a[i + k] + l[k];
+        }
+        if (sc >= 1)
+            for (int k = 0; k < 4; k++) l[k] *= SCALING_THRESHOLD;
+        prob_const += ((l[0] + l[1]) + (l[2] + l[3])) + ptn_invar[ptn];
+    }
+    free(val);
+    return prob_const;
+}
+
+/* The tail of computeLikelihoodDervEigenSIMD (phylokernel.h:655-725, no rescale there) and of
+ * computeLikelihoodFromBufferEigenSIMD (:1124-1187, rescale by sum_scale_num >= 1) on theta.
+ * out[0] = sum lh_ptn, out[1] = sum df_ptn, out[2] = sum ddf_ptn over the unobserved patterns. */
+void oracle_asc_theta_sums(int n, int ncat, size_t n_unobs, const double *eval, const double *rates,
+                           const double *props, double len, const double *theta,
+                           const short *sum_scale /* NULL: no rescale (Derv) */,
+                           const double *ptn_invar, double *out) {
+    size_t block = (size_t)n * ncat;
+    double *v0 = (double *)malloc(sizeof(double) * block * 3);
+    double *v1 = v0 + block, *v2 = v1 + block;
+    for (int c = 0; c < ncat; c++)
+        for (int i = 0; i < n; i++) {
+            double cof = eval[i] * rates[c];
+            double v = exp(cof * len) * props[c];
+            v0[c * n + i] = v;
+            v1[c * n + i] = cof * v;
+            v2[c * n + i] = cof * v1[c * n + i];
+        }
+    out[0] = out[1] = out[2] = 0.0;
+    for (size_t ptn = 0; ptn < n_unobs; ptn++) {
+        const double *th = theta + ptn * block;
+        double p[4], d1[4], d2[4];
+        for (int k = 0; k < 4; k++) { p[k] = v0[k] * th[k]; d1[k] = v1[k] * th[k]; d2[k] = v2[k] * th[k]; }
+        for (size_t i = 4; i < block; i += 4)
+            for (int k = 0; k < 4; k++) {
+                p[k] = th[i + k] * v0[i + k] + p[k];
+                d1[k] = th[i + k] * v1[i + k] + d1[k];
+                d2[k] = th[i + k] * v2[i + k] + d2[k];
+            }
+        if (sum_scale && sum_scale[ptn] >= 1)
+            for (int k = 0; k < 4; k++) p[k] *= SCALING_THRESHOLD;
+        out[0] += ((p[0] + p[1]) + (p[2] + p[3])) + ptn_invar[ptn];
+        out[1] += (d1[0] + d1[1]) + (d1[2] + d1[3]);
+        out[2] += (d2[0] + d2[1]) + (d2[2] + d2[3]);
+    }
+    free(v0);
+}

@@ -52,6 +52,11 @@ def lib():
     L.oracle_derv.restype = None
     L.oracle_lnl_from_theta.argtypes = [C.c_int, C.c_int, C.c_size_t, dp, dp, dp, C.c_double, dp, dp, dp, dp]
     L.oracle_lnl_from_theta.restype = C.c_double
+    L.oracle_asc_prob_const_branch.argtypes = [C.c_int, C.c_int, C.c_size_t, dp, dp, dp, C.c_double, dp, u8, dp, sp,
+                                               dp, sp, dp]
+    L.oracle_asc_prob_const_branch.restype = C.c_double
+    L.oracle_asc_theta_sums.argtypes = [C.c_int, C.c_int, C.c_size_t, dp, dp, dp, C.c_double, dp, sp, dp, dp]
+    L.oracle_asc_theta_sums.restype = None
     _LIB = L
     return L
 
@@ -113,12 +118,16 @@ def _parse_newick(s):
 class OracleTree:
     """Unrooted tree + alignment + model; partial vectors cached per directed edge."""
 
-    def __init__(self, newick, nstates, seq_type, states, ptn_freq, ptn_invar, model):
+    def __init__(self, newick, nstates, seq_type, states, ptn_freq, ptn_invar, model, n_unobs=0, nsites=None):
         self.L = lib()
         self.n = nstates
         self.seq_type = seq_type
         self.states = np.ascontiguousarray(states, dtype=np.uint8)
         self.ntaxa, self.nptn = self.states.shape
+        # +ASC: the last n_unobs patterns are the unobserved constant patterns (frequency 0)
+        self.n_unobs = int(n_unobs)
+        self.nobs = self.nptn - self.n_unobs
+        self.nsites = float(nsites if nsites is not None else np.sum(ptn_freq))
         self.freq = np.ascontiguousarray(ptn_freq, dtype=np.float64)
         self.invar = (np.zeros(self.nptn) if ptn_invar is None
                       else np.ascontiguousarray(ptn_invar, dtype=np.float64))
@@ -250,24 +259,38 @@ class OracleTree:
         return (None, plh, sc, sf)
 
     def _ends(self, a, b):
-        """(dad_states, dad_plh, node_plh, scale_factor_sum) with the leaf (if any) as dad."""
+        """(dad_states, dad_plh, node_plh, scale_factor_sum, dad_scale, node_scale), leaf (if any) as dad."""
         if self.is_leaf(b):
             a, b = b, a
         if self.is_leaf(a):
-            plh, _, sf = self.partial(a, b)
-            return self.states[a], None, plh, sf
-        pa, _, sfa = self.partial(b, a)
-        pb, _, sfb = self.partial(a, b)
-        return None, pa, pb, sfa + sfb
+            plh, sc, sf = self.partial(a, b)
+            return self.states[a], None, plh, sf, None, sc
+        pa, sca, sfa = self.partial(b, a)
+        pb, scb, sfb = self.partial(a, b)
+        return None, pa, pb, sfa + sfb, sca, scb
 
     def branch_lnl(self, a, b, length=None):
-        ds, dp_, np_, sf = self._ends(a, b)
+        ds, dp_, np_, sf, dsc, nsc = self._ends(a, b)
         ln = self.length(a, b) if length is None else length
         plh = np.zeros(self.nptn)
-        v = self.L.oracle_branch_lnl(self.n, self.ncat, self.nptn, _dp(self.eval), _dp(self.rates),
+        v = self.L.oracle_branch_lnl(self.n, self.ncat, self.nobs, _dp(self.eval), _dp(self.rates),
                                      _dp(self.props), ln, _dp(self.tip), _u8(ds), _dp(dp_), _dp(np_),
                                      _dp(self.freq), _dp(self.invar), _dp(plh))
-        return sf + v, plh
+        total = sf + v
+        if self.n_unobs:
+            o = self.nobs
+            pc = self.L.oracle_asc_prob_const_branch(
+                self.n, self.ncat, self.n_unobs, _dp(self.eval), _dp(self.rates), _dp(self.props), ln,
+                _dp(self.tip), _u8(None if ds is None else np.ascontiguousarray(ds[o:])),
+                _dp(None if dp_ is None else np.ascontiguousarray(dp_[o:])),
+                _sp(None if dsc is None else np.ascontiguousarray(dsc[o:])),
+                _dp(np.ascontiguousarray(np_[o:])), _sp(np.ascontiguousarray(nsc[o:])),
+                _dp(np.ascontiguousarray(self.invar[o:])))
+            assert 0.0 <= pc < 1.0
+            lp = np.log(1.0 - pc)  # phylokernel.h:1009-1016
+            plh[:o] -= lp
+            total -= self.nsites * lp
+        return total, plh
 
     def likelihood(self, root=0):
         """clearAllPartialLH(); computeLikelihood(): branch = farthest leaf's pendant branch."""
@@ -276,9 +299,10 @@ class OracleTree:
         return self.branch_lnl(leaf, nb)[0], (leaf, nb)
 
     def theta(self, a, b):
-        ds, dp_, np_, sf = self._ends(a, b)
+        ds, dp_, np_, sf, dsc, nsc = self._ends(a, b)
         th = np.zeros((self.nptn, self.block))
         self.L.oracle_theta(self.n, self.ncat, self.nptn, _dp(self.tip), _u8(ds), _dp(dp_), _dp(np_), _dp(th))
+        self._theta_scale = (nsc if dsc is None else (dsc + nsc)).astype(np.int16)
         return th, sf
 
     def derv(self, a, b, length=None, theta=None):
@@ -286,19 +310,41 @@ class OracleTree:
             theta, _ = self.theta(a, b)
         ln = self.length(a, b) if length is None else length
         df, ddf = C.c_double(), C.c_double()
-        self.L.oracle_derv(self.n, self.ncat, self.nptn, _dp(self.eval), _dp(self.rates), _dp(self.props),
+        self.L.oracle_derv(self.n, self.ncat, self.nobs, _dp(self.eval), _dp(self.rates), _dp(self.props),
                            ln, _dp(theta), _dp(self.freq), _dp(self.invar), C.byref(df), C.byref(ddf))
-        return df.value, ddf.value
+        df, ddf = df.value, ddf.value
+        if self.n_unobs:  # phylokernel.h:655-725
+            o = self.nobs
+            out = np.zeros(3)
+            self.L.oracle_asc_theta_sums(self.n, self.ncat, self.n_unobs, _dp(self.eval), _dp(self.rates),
+                                         _dp(self.props), ln, _dp(np.ascontiguousarray(theta[o:])), None,
+                                         _dp(np.ascontiguousarray(self.invar[o:])), _dp(out))
+            prob_const = 1.0 - out[0]
+            df_frac, ddf_frac = out[1] / prob_const, out[2] / prob_const
+            df += self.nsites * df_frac
+            ddf += self.nsites * (ddf_frac + df_frac * df_frac)
+        return df, ddf
 
     def lnl_from_theta(self, a, b, length=None, theta=None, sf=None):
         if theta is None:
             theta, sf = self.theta(a, b)
         ln = self.length(a, b) if length is None else length
         plh = np.zeros(self.nptn)
-        v = self.L.oracle_lnl_from_theta(self.n, self.ncat, self.nptn, _dp(self.eval), _dp(self.rates),
+        v = self.L.oracle_lnl_from_theta(self.n, self.ncat, self.nobs, _dp(self.eval), _dp(self.rates),
                                          _dp(self.props), ln, _dp(theta), _dp(self.freq), _dp(self.invar),
                                          _dp(plh))
-        return sf + v, plh
+        total = sf + v
+        if self.n_unobs:  # phylokernel.h:1124-1187
+            o = self.nobs
+            out = np.zeros(3)
+            self.L.oracle_asc_theta_sums(self.n, self.ncat, self.n_unobs, _dp(self.eval), _dp(self.rates),
+                                         _dp(self.props), ln, _dp(np.ascontiguousarray(theta[o:])),
+                                         _sp(np.ascontiguousarray(self._theta_scale[o:])),
+                                         _dp(np.ascontiguousarray(self.invar[o:])), _dp(out))
+            lp = np.log(1.0 - out[0])
+            total -= self.nsites * lp
+            plh[:o] -= lp
+        return total, plh
 
     def time_traversals(self, budget_s=15.0, min_reps=1):
         """cpu_baseline: repeat {clear; full traversal; root lnL}; returns (M upd/s, reps, seconds)."""

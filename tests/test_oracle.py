@@ -117,3 +117,50 @@ def test_oracle_on_reference_example_alignment(synth, oracle):
     lnl, _ = tree.likelihood()
     site = textbook.site_log_likelihoods(tree.adj, pat, model, 0, 18)
     assert abs(lnl - float((site * freq).sum())) <= 1e-9 * abs(lnl)
+
+
+def _asc_case(synth, oracle, n, ncat, seq_type, seed, pinvar=0.0):
+    """variable-sites-only alignment + the unobserved constant patterns appended (frequency 0)"""
+    if n == 4:
+        model = synth.gtr_model(alpha=0.9, ncat=ncat, pinvar=pinvar)
+    else:
+        model = synth.random_reversible_model(n, seed, alpha=0.9, ncat=ncat, pinvar=pinvar)
+    nwk = synth.random_tree_newick(8, seed, 0.02, 0.15)
+    st = synth.simulate_alignment(nwk, model, 400, seed + 1)
+    pat, freq = synth.compress_patterns(st)
+    const = np.all(pat == pat[0][None, :], axis=0)
+    pat, freq = np.ascontiguousarray(pat[:, ~const]), freq[~const].copy()
+    unobs = np.tile(np.arange(n, dtype=np.uint8)[None, :], (8, 1))   # one constant pattern per state
+    pat2 = np.ascontiguousarray(np.concatenate([pat, unobs], axis=1))
+    freq2 = np.concatenate([freq, np.zeros(n)])
+    invar = synth.ptn_invar_for(pat2, model)
+    return model, nwk, pat2, freq2, invar, n, float(freq.sum())
+
+
+@pytest.mark.parametrize("n,ncat,seq_type,pinvar", [(4, 4, 0, 0.0), (4, 4, 0, 0.15), (20, 4, 1, 0.0)])
+def test_oracle_ascertainment_bias_correction(synth, oracle, n, ncat, seq_type, pinvar):
+    """+ASC: lnL = sum_i f_i*(log L_i - log(1 - P(constant pattern))) (Lewis 2001), which is what
+    phylokernel.h:868-909,1009-1016 computes; checked against the probability-space textbook code."""
+    import textbook
+    model, nwk, pat, freq, invar, nun, nsites = _asc_case(synth, oracle, n, ncat, seq_type, 31 + n, pinvar)
+    tree = oracle.OracleTree(nwk, n, seq_type, pat, freq, invar, model, n_unobs=nun, nsites=nsites)
+    lnl, (a, b) = tree.likelihood()
+    su = oracle.state_unknown_for(n, seq_type)
+    site = np.exp(textbook.site_log_likelihoods(tree.adj, pat, model, seq_type, su)) + invar
+    pconst = site[-nun:].sum()
+    ref = float((freq[:-nun] * (np.log(site[:-nun]) - np.log(1.0 - pconst))).sum())
+    assert abs(lnl - ref) <= 1e-9 * abs(ref)
+    # every branch gives the same corrected lnL; K9 == K6; derivatives match finite differences
+    for x in tree.adj:
+        for y, _ in tree.adj[x]:
+            if x < y:
+                assert abs(tree.branch_lnl(x, y)[0] - lnl) <= 1e-9 * abs(lnl)
+    for (x, y) in [(a, b), (tree.ntaxa, tree.adj[tree.ntaxa][0][0])]:
+        t = tree.length(x, y)
+        th, sf = tree.theta(x, y)
+        f = lambda v: tree.lnl_from_theta(x, y, v, th, sf)[0]
+        assert abs(f(t) - lnl) <= 1e-9 * abs(lnl)
+        df, ddf = tree.derv(x, y, t, th)
+        h = 1e-5
+        np.testing.assert_allclose(df, (f(t + h) - f(t - h)) / (2 * h), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(ddf, (f(t + h) - 2 * f(t) + f(t - h)) / h ** 2, rtol=2e-3)

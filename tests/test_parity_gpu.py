@@ -550,3 +550,54 @@ def test_many_taxa_plan_chunks_and_key_reuse(pkg, synth, oracle):
         assert lib.iqhip_release(t.engine, k) == 0
     t.clear_all_partial_lh()
     assert abs(t.compute_likelihood() - lnl) <= 1e-12 * abs(lnl)
+
+
+# ------------------------------------------------------------------------------------------
+# +ASC: ascertainment-bias correction (phylokernel.h:655-725, 868-909, 968-1016, 1124-1187)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,ncat,seq_type,pinvar", [(4, 4, 0, 0.0), (4, 4, 0, 0.15), (20, 4, 1, 0.0), (64, 1, 2, 0.0)])
+def test_ascertainment_bias_correction(pkg, synth, oracle, n, ncat, seq_type, pinvar):
+    if n == 4:
+        model = synth.gtr_model(alpha=0.9, ncat=ncat, pinvar=pinvar)
+    else:
+        model = synth.random_reversible_model(n, 51, alpha=0.9 if ncat > 1 else None, ncat=ncat, pinvar=pinvar)
+    nwk = synth.random_tree_newick(9, 52, 0.02, 0.15)
+    st = synth.simulate_alignment(nwk, model, 500, 53)
+    pat, freq = synth.compress_patterns(st)
+    const = np.all(pat == pat[0][None, :], axis=0)
+    pat, freq = np.ascontiguousarray(pat[:, ~const]), freq[~const].copy()
+    nun, nsites = n, float(freq.sum())
+    pat = np.ascontiguousarray(np.concatenate([pat, np.tile(np.arange(n, dtype=np.uint8)[None, :], (9, 1))], axis=1))
+    freq = np.concatenate([freq, np.zeros(n)])
+    invar = synth.ptn_invar_for(pat, model)
+    ot = oracle.OracleTree(nwk, n, seq_type, pat, freq, invar, model, n_unobs=nun, nsites=nsites)
+    t = pkg.PhyloTree(nwk)
+    t.set_alignment(n, seq_type, pat, freq, invar)
+    t.set_ascertainment(nun, nsites)
+    t.set_model(model)
+    t.attach_engine(0)
+    lnl, plh = t.compute_likelihood(want_pattern_lh=True)
+    ref, (a, b) = ot.likelihood()
+    assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+    _, oplh = ot.branch_lnl(a, b)
+    np.testing.assert_allclose(plh[:-nun], oplh[:-nun], rtol=1e-10, atol=1e-10)
+    # uncorrected value differs, so the correction really took part
+    t.set_ascertainment(0, 0.0)
+    t.clear_all_partial_lh()
+    assert abs(t.compute_likelihood() - ref) > 1e-3
+    t.set_ascertainment(nun, nsites)
+    t.clear_all_partial_lh()
+    t.compute_likelihood()
+    for (x, y) in [(a, b), (t.num_leaves, t.neighbors(t.num_leaves)[0][0]), (t.num_leaves + 1, t.neighbors(t.num_leaves + 1)[1][0])]:
+        v = t.compute_likelihood_branch(x, y)
+        assert abs(v - ref) <= LNL_RTOL * abs(ref), (x, y)
+        t.reset_theta()
+        df, ddf = t.compute_likelihood_derv(x, y)
+        odf, oddf = ot.derv(x, y)
+        assert abs(df - odf) <= 1e-9 * max(1.0, abs(odf)) + 1e-12 * abs(oddf)
+        assert abs(ddf - oddf) <= 1e-9 * abs(oddf)
+        w = t.compute_likelihood_from_buffer()
+        o, _ = ot.lnl_from_theta(x, y)
+        assert abs(w - o) <= LNL_RTOL * abs(o)
+    # branch optimisation falls back to the host Newton loop under +ASC and still improves the lnL
+    assert t.optimize_all_branches(iterations=2, tolerance=1e-3) >= lnl - 1e-9 * abs(lnl)
