@@ -164,6 +164,7 @@ def libiqhost():
     lib.iqhost_optimize_one_branch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, dp]
     lib.iqhost_optimize_all_branches.argtypes = [vp, C.c_int, C.c_double, C.c_int, dp]
     lib.iqhost_set_branch_bounds.argtypes = [vp, C.c_double, C.c_double]
+    lib.iqhost_nni_for_branch.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
     lib.iqhost_tree_string.argtypes = [vp, C.c_char_p, C.c_int]
     lib.iqhost_fetch_scale_num.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int16)]
     lib.iqhost_fetch_partial.argtypes = [vp, C.c_int, C.c_int, dp]
@@ -373,6 +374,12 @@ class PhyloTree:
         lnl = C.c_double()
         self._chk(self.lib.iqhost_optimize_all_branches(self.h, iterations, tolerance, max_nr_step, C.byref(lnl)))
         return lnl.value
+
+    def nni_for_branch(self, a, b, nni5=False):
+        """getBestNNIForBran: [(newloglh, swapped subtree at a, swapped subtree at b, [newLen...]), x2]"""
+        out = np.zeros(16)
+        self._chk(self.lib.iqhost_nni_for_branch(self.h, a, b, int(nni5), _dptr(out)))
+        return [(out[8 * c], int(out[8 * c + 1]), int(out[8 * c + 2]), list(out[8 * c + 3:8 * c + 8])) for c in range(2)]
 
     def set_branch_bounds(self, lo, hi):
         self._chk(self.lib.iqhost_set_branch_bounds(self.h, lo, hi))

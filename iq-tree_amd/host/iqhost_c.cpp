@@ -166,6 +166,20 @@ int iqhost_optimize_one_branch(void *h, int a, int b, int clear_lh, int max_nr_s
 int iqhost_optimize_all_branches(void *h, int iterations, double tolerance, int max_nr_step, double *lnl) {
     IQHOST_TRY(*lnl = ((PhyloTree *)h)->optimizeAllBranches(iterations, tolerance, max_nr_step));
 }
+// both NNI moves around the internal branch (a, b): out[cnt*8 + {0:newloglh, 1:node1_nei, 2:node2_nei, 3..7:newLen}]
+int iqhost_nni_for_branch(void *h, int a, int b, int nni5, double *out) {
+    IQHOST_TRY({
+        PhyloTree *t = (PhyloTree *)h;
+        PhyloTree::NNIMove mv[2];
+        t->getBestNNIForBran(t->nodes[a], t->nodes[b], nni5 != 0, mv);
+        for (int c = 0; c < 2; c++) {
+            out[c * 8 + 0] = mv[c].newloglh;
+            out[c * 8 + 1] = mv[c].node1_nei;
+            out[c * 8 + 2] = mv[c].node2_nei;
+            for (int k = 0; k < 5; k++) out[c * 8 + 3 + k] = mv[c].newLen[k];
+        }
+    });
+}
 int iqhost_set_branch_bounds(void *h, double minlen, double maxlen) {
     IQHOST_TRY({
         ((PhyloTree *)h)->min_branch_length = minlen;

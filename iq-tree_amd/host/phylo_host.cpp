@@ -784,6 +784,112 @@ double PhyloTree::optimizeAllBranches(int my_iterations, double tolerance, int m
 }
 
 // =========================================================================================
+// NNI evaluation, phylotree.cpp:2873-3066 (upper-bound shortcut and ptnlh output left out)
+// =========================================================================================
+static void updateNeighborNode(PhyloNode *at, PhyloNode *oldn, PhyloNode *newn) {
+    for (PhyloNeighbor *nb : at->neighbors)
+        if (nb->node == oldn) { nb->node = newn; return; }
+    throw std::runtime_error("updateNeighbor: not adjacent");
+}
+
+PhyloTree::NNIMove PhyloTree::getBestNNIForBran(PhyloNode *node1, PhyloNode *node2, bool nni5, NNIMove moves[2]) {
+    if (node1->isLeaf() || node2->isLeaf() || node1->degree() != 3 || node2->degree() != 3)
+        throw std::runtime_error("getBestNNIForBran needs an internal branch of a binary tree");
+    if (!central_partial_lh) initializeAllPartialLh();
+    const int IT_NUM = nni5 ? 6 : 2;
+    if (!nni_keys[0])
+        for (int i = 0; i < 6; i++) nni_keys[i] = next_key++;
+    // the neighbour slots that get a scratch copy (:2901-2924)
+    std::vector<PhyloNeighbor **> slot;
+    auto slot_of = [](PhyloNode *at, PhyloNode *to) -> PhyloNeighbor ** {
+        for (auto &nb : at->neighbors)
+            if (nb->node == to) return &nb;
+        throw std::runtime_error("not adjacent");
+    };
+    slot.push_back(slot_of(node1, node2));
+    slot.push_back(slot_of(node2, node1));
+    if (nni5) {
+        for (PhyloNeighbor *nb : node1->neighbors) if (nb->node != node2) slot.push_back(slot_of(nb->node, node1));
+        for (PhyloNeighbor *nb : node2->neighbors) if (nb->node != node1) slot.push_back(slot_of(nb->node, node2));
+    }
+    std::vector<PhyloNeighbor *> saved(IT_NUM);
+    for (int id = 0; id < IT_NUM; id++) {
+        saved[id] = *slot[id];
+        PhyloNeighbor *tmp = new PhyloNeighbor();
+        tmp->node = saved[id]->node;
+        tmp->length = saved[id]->length;
+        tmp->id = saved[id]->id;
+        tmp->partial_lh = nni_keys[id];
+        *slot[id] = tmp;
+    }
+    PhyloNeighbor *node12_it = node1->findNeighbor(node2), *node21_it = node2->findNeighbor(node1);
+
+    // the two moves: first non-node2 neighbour of node1 against each non-node1 neighbour of node2 (:2951-2960)
+    size_t i1 = 0;
+    while (node1->neighbors[i1]->node == node2) i1++;
+    std::vector<size_t> i2s;
+    for (size_t j = 0; j < node2->neighbors.size(); j++)
+        if (node2->neighbors[j]->node != node1) i2s.push_back(j);
+    const double backupScore = curScore;
+    for (int cnt = 0; cnt < 2; cnt++) {
+        const size_t i2 = i2s[cnt];
+        PhyloNeighbor *node1_nei = node1->neighbors[i1], *node2_nei = node2->neighbors[i2];
+        moves[cnt] = NNIMove();
+        moves[cnt].node1 = node1->id;
+        moves[cnt].node2 = node2->id;
+        moves[cnt].node1_nei = node1_nei->node->id;
+        moves[cnt].node2_nei = node2_nei->node->id;
+        // do the NNI swap (:2976-2980)
+        node1->neighbors[i1] = node2_nei;
+        updateNeighborNode(node2_nei->node, node2, node1);
+        node2->neighbors[i2] = node1_nei;
+        updateNeighborNode(node1_nei->node, node1, node2);
+        node12_it->clearPartialLh();
+        node21_it->clearPartialLh();
+        int i = 1;
+        if (nni5) {
+            for (PhyloNeighbor *nb : std::vector<PhyloNeighbor *>(node1->neighbors))
+                if (nb->node != node2) {
+                    nb->node->findNeighbor(node1)->clearPartialLh();
+                    optimizeOneBranch(node1, nb->node, false, NNI_MAX_NR_STEP);
+                    moves[cnt].newLen[i++] = node1->findNeighbor(nb->node)->length;
+                }
+            node21_it->clearPartialLh();
+        }
+        optimizeOneBranch(node1, node2, false, NNI_MAX_NR_STEP);
+        moves[cnt].newLen[0] = node1->findNeighbor(node2)->length;
+        if (nni5) {
+            for (PhyloNeighbor *nb : std::vector<PhyloNeighbor *>(node2->neighbors))
+                if (nb->node != node1) {
+                    nb->node->findNeighbor(node2)->clearPartialLh();
+                    optimizeOneBranch(node2, nb->node, false, NNI_MAX_NR_STEP);
+                    moves[cnt].newLen[i++] = node2->findNeighbor(nb->node)->length;
+                }
+            node12_it->clearPartialLh();
+        }
+        moves[cnt].newloglh = computeLikelihoodFromBuffer();
+        // swap back (:3027-3030)
+        node1->neighbors[i1] = node1_nei;
+        updateNeighborNode(node1_nei->node, node2, node1);
+        node2->neighbors[i2] = node2_nei;
+        updateNeighborNode(node2_nei->node, node1, node2);
+    }
+    // restore the Neighbor objects (:3036-3044)
+    for (int id = IT_NUM - 1; id >= 0; id--) {
+        if (*slot[id] == current_it) current_it = saved[id];
+        if (*slot[id] == current_it_back) current_it_back = saved[id];
+        delete *slot[id];
+        *slot[id] = saved[id];
+    }
+    // restore the length of the 4 branches around node1, node2 (:3048-3051)
+    for (PhyloNeighbor *nb : node1->neighbors) if (nb->node != node2) nb->length = nb->node->findNeighbor(node1)->length;
+    for (PhyloNeighbor *nb : node2->neighbors) if (nb->node != node1) nb->length = nb->node->findNeighbor(node2)->length;
+    theta_computed = false;
+    curScore = backupScore;
+    return moves[0].newloglh > moves[1].newloglh ? moves[0] : moves[1];
+}
+
+// =========================================================================================
 // host views
 // =========================================================================================
 void PhyloTree::fetchScaleNum(PhyloNeighbor *nei, UBYTE *out) {

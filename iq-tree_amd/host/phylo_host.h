@@ -145,6 +145,17 @@ public:
     void optimizeOneBranch(PhyloNode *node1, PhyloNode *node2, bool clearLH = true, int maxNRStep = 100);
     double optimizeAllBranches(int my_iterations = 100, double tolerance = 0.001, int maxNRStep = 100);
 
+    // ---- NNI evaluation (phylotree.cpp:2873-3066): both swaps around an internal branch, the central
+    //      branch (and with nni5 the four adjacent ones) re-optimised on scratch buffers, tree restored
+    struct NNIMove {
+        int node1 = -1, node2 = -1;
+        int node1_nei = -1, node2_nei = -1;  // the two subtrees (by their root node id) that were swapped
+        double newloglh = 0.0;
+        double newLen[5] = {0, 0, 0, 0, 0};
+    };
+    NNIMove getBestNNIForBran(PhyloNode *node1, PhyloNode *node2, bool nni5, NNIMove moves[2]);
+    static const int NNI_MAX_NR_STEP = 10;  // phylotree.h
+
     // ---- host views ----------------------------------------------------------------------
     void fetchScaleNum(PhyloNeighbor *nei, UBYTE *out);
     void fetchPartialLh(PhyloNeighbor *nei, double *out);
@@ -185,6 +196,7 @@ private:
     bool dry_run = false;
     bool inputs_dirty = true;
     uint64_t next_key = 1;
+    uint64_t nni_keys[6] = {0, 0, 0, 0, 0, 0};  // nni_partial_lh scratch (phylotree.cpp:852-860)
     std::vector<uint8_t> aln_states;
     std::vector<double> ptn_freq, ptn_invar, m_eval, m_evec, m_inv_evec, m_rates, m_props;
     std::vector<PhyloNeighbor *> all_neighbors;

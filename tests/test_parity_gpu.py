@@ -601,3 +601,49 @@ def test_ascertainment_bias_correction(pkg, synth, oracle, n, ncat, seq_type, pi
         assert abs(w - o) <= LNL_RTOL * abs(o)
     # branch optimisation falls back to the host Newton loop under +ASC and still improves the lnL
     assert t.optimize_all_branches(iterations=2, tolerance=1e-3) >= lnl - 1e-9 * abs(lnl)
+
+
+@pytest.mark.parametrize("nni5", [False, True])
+def test_nni_evaluation_on_scratch_buffers(pkg, synth, oracle, nni5):
+    """getBestNNIForBran (phylotree.cpp:2873-3066): the search re-points neighbours at scratch buffers,
+    swaps subtrees, re-optimises branches and restores everything.  Each move's lnL must be the lnL of
+    the swapped topology (with the lengths the move reports) as the oracle computes it from scratch,
+    and the tree must be intact afterwards."""
+    t, ot, model, pat, freq = make_case(synth, oracle, pkg, 10, 500, 4, 4, 1001)
+    base = t.compute_likelihood()
+    ref0, _ = ot.likelihood()
+    internal = [(a, b) for a in range(t.num_leaves, t.num_nodes) for b, _ in t.neighbors(a)
+                if b >= t.num_leaves and a < b]
+    assert internal
+    for (a, b) in internal[:4]:
+        moves = t.nni_for_branch(a, b, nni5=nni5)
+        for (lnl, sa, sb, lens) in moves:
+            # oracle on the swapped topology: subtree sa (was at a) <-> subtree sb (was at b)
+            adj = {k: [list(e) for e in v] for k, v in ot.adj.items()}
+            la = [e for e in adj[a] if e[0] == sa][0]
+            lb = [e for e in adj[b] if e[0] == sb][0]
+            adj[a].remove(la); adj[b].remove(lb)
+            adj[a].append([sb, lb[1]]); adj[b].append([sa, la[1]])
+            for e in adj[sa]:
+                if e[0] == a: e[0] = b
+            for e in adj[sb]:
+                if e[0] == b: e[0] = a
+            o2 = oracle.OracleTree("(0:1,1:1,2:1);", 4, 0, pat, freq, None, model)
+            o2.adj = adj
+            o2.ntaxa = ot.ntaxa
+            o2.set_length(a, b, lens[0])
+            if nni5:  # newLen[1..2]: branches of a (other than b) in stored order, [3..4]: of b
+                k = 1
+                # the mirror reports lengths in its neighbour order after the swap; recover by name
+                na = [sb if x == sa else x for x, _ in t.neighbors(a) if x != b]
+                nb_ = [sa if x == sb else x for x, _ in t.neighbors(b) if x != a]
+                for x in na:
+                    o2.set_length(a, x, lens[k]); k += 1
+                for x in nb_:
+                    o2.set_length(b, x, lens[k]); k += 1
+            ref, _ = o2.branch_lnl(a, b)
+            assert abs(lnl - ref) <= 1e-8 * abs(ref), (a, b, sa, sb, lnl, ref)
+        # tree restored: same lnL, same branch lengths
+        t.clear_all_partial_lh()
+        assert abs(t.compute_likelihood() - base) <= 1e-12 * abs(base)
+    assert abs(base - ref0) <= LNL_RTOL * abs(ref0)
