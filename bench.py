@@ -136,9 +136,8 @@ def main():
             dist.all_reduce(res[:n], op=dist.ReduceOp.SUM)
         tree.set_allreduce_hook(hook)
 
-    def step():
-        tree.clear_all_partial_lh()
-        return tree.compute_likelihood()
+    def step():  # clearAllPartialLH(); computeLikelihood() on the C++ side of the boundary
+        return tree.clear_and_compute_likelihood()
 
     def barrier():
         torch.cuda.synchronize()

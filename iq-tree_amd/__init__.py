@@ -155,6 +155,7 @@ def libiqhost():
     lib.iqhost_initialize_all_partial_lh.argtypes = [vp]
     lib.iqhost_clear_all_partial_lh.argtypes = [vp]
     lib.iqhost_compute_likelihood.argtypes = [vp, dp, dp]
+    lib.iqhost_clear_and_compute_likelihood.argtypes = [vp, dp]
     lib.iqhost_current_branch.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.iqhost_compute_partial.argtypes = [vp, C.c_int, C.c_int]
     lib.iqhost_compute_branch.argtypes = [vp, C.c_int, C.c_int, dp]
@@ -336,6 +337,12 @@ class PhyloTree:
             self._chk(self.lib.iqhost_compute_likelihood(self.h, C.byref(lnl), _dptr(plh)))
             return lnl.value, plh
         self._chk(self.lib.iqhost_compute_likelihood(self.h, C.byref(lnl), None))
+        return lnl.value
+
+    def clear_and_compute_likelihood(self):
+        """clearAllPartialLH(); computeLikelihood() -- the model optimisers' target function"""
+        lnl = C.c_double()
+        self._chk(self.lib.iqhost_clear_and_compute_likelihood(self.h, C.byref(lnl)))
         return lnl.value
 
     def current_branch(self):

@@ -145,7 +145,7 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
         if (s.sc) hipFree(s.sc);
     }
     void *ptrs[] = {e->d_states, e->d_freq, e->d_invar, e->d_eval, e->d_evec, e->d_inv_evec,
-                    e->d_rates, e->d_props, e->d_tip, e->d_ops, e->d_val, e->d_slab,
+                    e->d_rates, e->d_props, e->d_tip, e->d_ops, e->d_slab,
                     e->d_theta, e->d_pattern_lh, e->dummy.plh, e->dummy.sc, e->d_newton_partials,
                     e->d_newton_barrier};
     for (void *p : ptrs)
@@ -205,6 +205,7 @@ static int slab_for_key(iqhip_engine *e, uint64_t key, bool create, int *idx) {
     int rc = new_slab(e, idx);
     if (rc) return rc;
     e->key2slab[key] = *idx;
+    e->keymap_version++;
     return IQHIP_OK;
 }
 
@@ -231,6 +232,7 @@ extern "C" int iqhip_release(iqhip_engine *e, uint64_t key) {
     if (it == e->key2slab.end()) return IQHIP_OK;
     e->free_slabs.push_back(it->second);
     e->key2slab.erase(it);
+    e->keymap_version++;
     return IQHIP_OK;
 }
 
@@ -243,6 +245,7 @@ extern "C" int iqhip_rekey(iqhip_engine *e, uint64_t old_key, uint64_t new_key) 
     int idx = it->second;
     e->key2slab.erase(it);
     e->key2slab[new_key] = idx;
+    e->keymap_version++;
     return IQHIP_OK;
 }
 
@@ -393,6 +396,15 @@ static int resolve_child(iqhip_engine *e, uint64_t key, int32_t leaf, int prev_d
 static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *last_dst) {
     constexpr int kSentinels = 2;  // >= the kernels' deepest look-ahead (streamed child: 1 op)
     if (nops + 2 > e->result_cap) return fail(IQHIP_ERR_INVALID, "too many node updates in one submission");
+    // Same op list as last time and no key created / released / moved since: the descriptors on
+    // the device are still the right ones (hot loop 1 re-evaluates one tree many times).
+    const size_t in_bytes = sizeof(iqhip_node_op) * (size_t)nops;
+    if (nops > 0 && e->last_plan_version == e->keymap_version && e->last_ops_in.size() == in_bytes &&
+        memcmp(e->last_ops_in.data(), ops, in_bytes) == 0 && !e->uploaded_plan.empty()) {
+        *last_dst = e->last_plan_dst;
+        return IQHIP_OK;
+    }
+    e->last_plan_version = 0;
     int rc = ensure_plan_capacity(e, nops + kSentinels);
     if (rc) return rc;
     if (e->staging_busy) {  // the previous submission may still be copying h_ops
@@ -536,6 +548,9 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
     // the descriptors of a repeated plan (model-parameter optimisation re-evaluates the same
     // tree) are already on the device: skip the upload, never the computation
     const size_t nbytes = sizeof(DevOp) * (size_t)(nops + kSentinels);
+    e->last_ops_in.assign((const char *)ops, (const char *)ops + in_bytes);
+    e->last_plan_version = e->keymap_version;  // (slabs created while building are included)
+    e->last_plan_dst = prev_dst;
     if (e->uploaded_plan.size() == nbytes && memcmp(e->uploaded_plan.data(), e->h_ops, nbytes) == 0)
         return IQHIP_OK;
     HIPCHK(hipMemcpyAsync(e->d_ops, e->h_ops, nbytes, hipMemcpyHostToDevice, e->stream));

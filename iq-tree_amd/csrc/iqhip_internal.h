@@ -112,7 +112,6 @@ struct iqhip_engine {
     // per-call buffers
     iqhip::DevOp *d_ops = nullptr;
     int ops_cap = 0;
-    double *d_val = nullptr;    // 3*block doubles: val0,val1,val2 for branch kernels
     double *d_slab = nullptr;   // wave partials [nvals][nwaves]
     int64_t slab_cap = 0;
     double *d_theta = nullptr, *d_pattern_lh = nullptr;
@@ -125,6 +124,11 @@ struct iqhip_engine {
     iqhip::DevOp *h_ops = nullptr;
     double *h_result = nullptr;
     std::vector<char> uploaded_plan;  // bytes of the descriptors currently in d_ops
+    // the caller's op list the current descriptors were built from: an identical list (same keys,
+    // leaves, lengths) with an unchanged key map needs no rebuilding at all
+    std::vector<char> last_ops_in;
+    uint64_t keymap_version = 1, last_plan_version = 0;
+    int last_plan_dst = -1;
     hipEvent_t staging_free = nullptr;
     bool staging_busy = false;
 

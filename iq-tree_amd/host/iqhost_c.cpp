@@ -121,6 +121,14 @@ int iqhost_neighbor_info(void *h, int from, int to, int *computed, uint64_t *key
 
 int iqhost_initialize_all_partial_lh(void *h) { IQHOST_TRY(((PhyloTree *)h)->initializeAllPartialLh()); }
 int iqhost_clear_all_partial_lh(void *h) { IQHOST_TRY(((PhyloTree *)h)->clearAllPartialLH()); }
+// hot loop 1 in one call: clearAllPartialLH(); computeLikelihood()  (model/modelgtr.cpp:510-518)
+int iqhost_clear_and_compute_likelihood(void *h, double *lnl) {
+    IQHOST_TRY({
+        PhyloTree *t = (PhyloTree *)h;
+        t->clearAllPartialLH();
+        *lnl = t->computeLikelihood(nullptr);
+    });
+}
 int iqhost_compute_likelihood(void *h, double *lnl, double *pattern_lh) {
     IQHOST_TRY(*lnl = ((PhyloTree *)h)->computeLikelihood(pattern_lh));
 }
