@@ -296,6 +296,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
             }
             if (!leafR) sc += prev_sc;
             const bool unkL = leafL && sL == A.state_unknown, unkR = leafR && sR == A.state_unknown;
+            const bool anyUnk = __any(unkL || unkR);
             const double *vnow = op.pf + ((op.real_mask & 1) ? tbase : dbase * 0);
             (void)vnow;
             double *dst = op.dst + tbase;
@@ -348,14 +349,19 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
                     }
                 }
                 v4f64 T[MT];
+                if (anyUnk) {  // wave-uniform: some lane holds an unknown state (gap) at a leaf child
 #pragma unroll
-                for (int m = 0; m < MT; m++)
+                    for (int m = 0; m < MT; m++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const double a = unkL ? 1.0 : YL[m][r];
-                        const double b = unkR ? 1.0 : YR[m][r];
-                        T[m][r] = a * b;
-                    }
+                        for (int r = 0; r < 4; r++) {
+                            const double a = unkL ? 1.0 : YL[m][r];
+                            const double b = unkR ? 1.0 : YR[m][r];
+                            T[m][r] = a * b;
+                        }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MT; m++) T[m] = YL[m] * YR[m];
+                }
                 v4f64 O[MT];
 #pragma unroll
                 for (int m = 0; m < MT; m++) O[m] = (v4f64){0, 0, 0, 0};
