@@ -510,7 +510,8 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         int budget;
         if (e->mfma) {
             const int MT = (e->n + 15) / 16, KS = e->n / 4;
-            const int fixed = 2 * MT * KS * 64 + (e->state_unknown + 1 - e->n) * e->n;
+            const int fixed = (e->mfma_pipelined ? mfma2_fixed_lds_doubles(e->n) : 2 * MT * KS * 64) +
+                              (e->state_unknown + 1 - e->n) * e->n;
             // two workgroups per CU (160 KB LDS): <= 78 KB each, images included
             budget = (78 * 1024) / 8 - fixed;
         } else {

@@ -159,6 +159,7 @@ hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, d
 
 // kernels_mfma.hip (nstates 20 / 64)
 hipError_t launch_traverse_mfma(iqhip_engine *e, int nops, int nwaves);
+int mfma2_fixed_lds_doubles(int n);
 // mode 0: branch lnL, 1: theta, 2: df/ddf from theta, 3: lnL from theta
 hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, double len, int nwaves);
 

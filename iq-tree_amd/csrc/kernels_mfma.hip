@@ -206,24 +206,47 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
 // ---------------------------------------------------------------------------------------
 template <int N, int C, int WG>
 __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
-    constexpr int MT = (N + 15) / 16;
+    // rows of U / U^-1: MTF full 16-row tiles on v_mfma_f64_16x16x4_f64 plus, for N = 20, the four
+    // left-over rows on v_mfma_f64_4x4x4_4b_f64 (4 blocks = the tile's 4 groups of 4 patterns).
+    // Lane layouts of the 4x4x4 form (measured, tools/mfma444_probe.hip): A[i][k] at lane
+    // 16k+4blk+i, B[k][j] at 16k+4blk+j, D[i][j] at 16i+4blk+j -- i.e. its B operand and its D
+    // result coincide with the 16x16x4 B fragment and with accumulator register 0 of a 16-row
+    // tile, so the tail needs no lane movement and no padding (23 vs 71.5 cycles per instruction).
+    constexpr int MTF = N / 16;
+    constexpr bool TAIL4 = (N % 16) == 4;
+    static_assert(N % 16 == 0 || TAIL4, "N must be 16m or 16m+4");
     constexpr int KS = N / 4;
     constexpr int WPB = WG / 64;
     constexpr int B = C * N;
-    constexpr bool A_IN_REGS = false;  // A fragments from the LDS image: registers buy occupancy 2
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *sU = smem;
-    double *sUi = sU + MT * KS * 64;
-    double *sTipx = sUi + MT * KS * 64;
+    double *sU = smem;                           // [MTF][KS][64]
+    double *sUi = sU + MTF * KS * 64;            // [MTF][KS][64]
+    double *sU4 = sUi + MTF * KS * 64;           // [KS][64] tail rows (TAIL4)
+    double *sUi4 = sU4 + (TAIL4 ? KS * 64 : 0);
+    // tip_partial_lh rows of states < N (= columns of U^-1): a plain [N][N] copy when it is small,
+    // otherwise read out of the U^-1 fragment image
+    constexpr bool TIP_COPY = (N * N * 8 <= 4096);
+    double *sUiT = sUi4 + (TAIL4 ? KS * 64 : 0);
+    double *sTipx = sUiT + (TIP_COPY ? N * N : 0);
     const int nx = A.state_unknown + 1 - N;
     double *sReg = sTipx + nx * N;
 
-    for (int t = threadIdx.x; t < MT * KS * 64; t += WG) {
+    for (int t = threadIdx.x; t < MTF * KS * 64; t += WG) {
         const int l = t & 63, ms = t >> 6, s = ms % KS, m = ms / KS;
         const int row = 16 * m + (l & 15), k = 4 * s + (l >> 4);
-        sU[t] = row < N ? A.evec[row * N + k] : 0.0;
-        sUi[t] = row < N ? A.inv_evec[row * N + k] : 0.0;
+        sU[t] = A.evec[row * N + k];
+        sUi[t] = A.inv_evec[row * N + k];
     }
+    if (TAIL4) {
+        for (int t = threadIdx.x; t < KS * 64; t += WG) {
+            const int l = t & 63, s = t >> 6;
+            const int row = 16 * MTF + (l & 3), k = 4 * s + (l >> 4);
+            sU4[t] = A.evec[row * N + k];
+            sUi4[t] = A.inv_evec[row * N + k];
+        }
+    }
+    if (TIP_COPY)
+        for (int t = threadIdx.x; t < N * N; t += WG) sUiT[t] = A.tip[t];  // tip[state][i] = U^-1[i][state]
     for (int t = threadIdx.x; t < nx * N; t += WG) sTipx[t] = A.tip[N * N + t];
 
     const int lane = threadIdx.x & 63;
@@ -234,16 +257,18 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
     const int p = lane & 15, g = lane >> 4;
     const int64_t ptn = tl * 16 + p;
     const size_t tbase = (size_t)tl * 16 * B;     // doubles into a vector slab
-    const size_t dbase = (size_t)lane;            // dummy window: first tile only
     const double freq = A.freq[ptn];
     const double invar = A.invar[ptn];
     const DevOp *ops = A.ops;
 
-    v4f64 prev[C][MT];
+    v4f64 prev[C][MTF];
+    double prevT[C];  // tail rows 16*MTF+g
 #pragma unroll
-    for (int c = 0; c < C; c++)
+    for (int c = 0; c < C; c++) {
+        prevT[c] = 0.0;
 #pragma unroll
-        for (int m = 0; m < MT; m++) prev[c][m] = (v4f64){0, 0, 0, 0};
+        for (int m = 0; m < MTF; m++) prev[c][m] = (v4f64){0, 0, 0, 0};
+    }
     int prev_sc = 0;
     double PFn[KS];
     int pfn_sc = 0;
@@ -252,16 +277,6 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
 #pragma unroll
         for (int s = 0; s < KS; s++) PFn[s] = src[s * 64 + lane];
         if (g == 0) pfn_sc = ops[0].pf_sc[(ops[0].real_mask & 1) ? ptn : (int64_t)p];
-    }
-
-    double aU[A_IN_REGS ? MT * KS : 1], aUi[A_IN_REGS ? MT * KS : 1];
-    __syncthreads();
-    if (A_IN_REGS) {
-#pragma unroll
-        for (int q = 0; q < MT * KS; q++) {
-            aU[q] = sU[q * 64 + lane];
-            aUi[q] = sUi[q * 64 + lane];
-        }
     }
 
     int k = 0;
@@ -291,14 +306,21 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
 #pragma unroll
                 for (int c = 0; c < C; c++)
 #pragma unroll
-                    for (int s = 0; s < KS; s++) prev[c][s >> 2][s & 3] = src[(size_t)c * N * 16 + s * 64 + lane];
+                    for (int s = 0; s < KS; s++) {
+                        const double v = src[(size_t)c * N * 16 + s * 64 + lane];
+                        if (s < 4 * MTF) prev[c][s >> 2][s & 3] = v; else prevT[c] = v;
+                    }
                 if (g == 0) prev_sc = op.ld_sc[ptn];
             }
             if (!leafR) sc += prev_sc;
             const bool unkL = leafL && sL == A.state_unknown, unkR = leafR && sR == A.state_unknown;
             const bool anyUnk = __any(unkL || unkR);
-            const double *vnow = op.pf + ((op.real_mask & 1) ? tbase : dbase * 0);
-            (void)vnow;
+            // tip_partial_lh row of this lane's pattern state (phylotreesse.cpp:464-527)
+            auto tip_at = [&](int st, int i) -> double {
+                if (st >= N) return sTipx[(st - N) * N + i];
+                if (TIP_COPY) return sUiT[st * N + i];
+                return sUi[aidx<KS>(i >> 4, st >> 2, (st & 3) * 16 + (i & 15))];  // U^-1[i][st] in the A image
+            };
             double *dst = op.dst + tbase;
             double lmax = 0.0;
 #pragma unroll
@@ -318,73 +340,80 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
                 }
                 if (leafL) {
 #pragma unroll
-                    for (int s = 0; s < KS; s++) {
-                        const int i = 4 * s + g;
-                        bl[s] = sL < N ? sUi[aidx<KS>(i >> 4, sL >> 2, (sL & 3) * 16 + (i & 15))] : sTipx[(sL - N) * N + i];
-                    }
+                    for (int s = 0; s < KS; s++) bl[s] = tip_at(sL, 4 * s + g);
                 }
                 if (leafR) {
 #pragma unroll
-                    for (int s = 0; s < KS; s++) {
-                        const int i = 4 * s + g;
-                        br[s] = sR < N ? sUi[aidx<KS>(i >> 4, sR >> 2, (sR & 3) * 16 + (i & 15))] : sTipx[(sR - N) * N + i];
-                    }
+                    for (int s = 0; s < KS; s++) br[s] = tip_at(sR, 4 * s + g);
                 } else {
 #pragma unroll
-                    for (int s = 0; s < KS; s++) br[s] = prev[c][s >> 2][s & 3];
+                    for (int s = 0; s < KS; s++) br[s] = (s < 4 * MTF) ? prev[c][(s >> 2) < MTF ? (s >> 2) : 0][s & 3] : prevT[c];
                 }
-                v4f64 YL[MT], YR[MT];
+                v4f64 YL[MTF], YR[MTF];
+                double yl4 = 0.0, yr4 = 0.0;
 #pragma unroll
-                for (int m = 0; m < MT; m++) { YL[m] = (v4f64){0, 0, 0, 0}; YR[m] = (v4f64){0, 0, 0, 0}; }
+                for (int m = 0; m < MTF; m++) { YL[m] = (v4f64){0, 0, 0, 0}; YR[m] = (v4f64){0, 0, 0, 0}; }
 #pragma unroll
                 for (int s = 0; s < KS; s++) {
                     const int i = 4 * s + g;
                     const double xl = bl[s] * exL[c * N + i];
                     const double xr = br[s] * exR[c * N + i];
 #pragma unroll
-                    for (int m = 0; m < MT; m++) {
-                        const double a = A_IN_REGS ? aU[A_IN_REGS ? m * KS + s : 0] : sU[aidx<KS>(m, s, lane)];
+                    for (int m = 0; m < MTF; m++) {
+                        const double a = sU[aidx<KS>(m, s, lane)];
                         YL[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xl, YL[m], 0, 0, 0);
                         YR[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xr, YR[m], 0, 0, 0);
                     }
+                    if (TAIL4) {
+                        const double a4 = sU4[s * 64 + lane];
+                        yl4 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4, xl, yl4, 0, 0, 0);
+                        yr4 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4, xr, yr4, 0, 0, 0);
+                    }
                 }
-                v4f64 T[MT];
+                v4f64 T[MTF];
+                double t4;
                 if (anyUnk) {  // wave-uniform: some lane holds an unknown state (gap) at a leaf child
 #pragma unroll
-                    for (int m = 0; m < MT; m++)
+                    for (int m = 0; m < MTF; m++)
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             const double a = unkL ? 1.0 : YL[m][r];
                             const double b = unkR ? 1.0 : YR[m][r];
                             T[m][r] = a * b;
                         }
+                    t4 = (unkL ? 1.0 : yl4) * (unkR ? 1.0 : yr4);
                 } else {
 #pragma unroll
-                    for (int m = 0; m < MT; m++) T[m] = YL[m] * YR[m];
+                    for (int m = 0; m < MTF; m++) T[m] = YL[m] * YR[m];
+                    t4 = yl4 * yr4;
                 }
-                v4f64 O[MT];
+                v4f64 O[MTF];
+                double o4 = 0.0;
 #pragma unroll
-                for (int m = 0; m < MT; m++) O[m] = (v4f64){0, 0, 0, 0};
+                for (int m = 0; m < MTF; m++) O[m] = (v4f64){0, 0, 0, 0};
 #pragma unroll
                 for (int s = 0; s < KS; s++) {
-                    const double bt = T[s >> 2][s & 3];
+                    // accumulator layout == B layout of k-step s (tail: the 4x4x4 result == k-step 4*MTF)
+                    const double bt = (s < 4 * MTF) ? T[(s >> 2) < MTF ? (s >> 2) : 0][s & 3] : t4;
 #pragma unroll
-                    for (int m = 0; m < MT; m++) {
-                        const double a = A_IN_REGS ? aUi[A_IN_REGS ? m * KS + s : 0] : sUi[aidx<KS>(m, s, lane)];
-                        O[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bt, O[m], 0, 0, 0);
-                    }
+                    for (int m = 0; m < MTF; m++)
+                        O[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(sUi[aidx<KS>(m, s, lane)], bt, O[m], 0, 0, 0);
+                    if (TAIL4) o4 = __builtin_amdgcn_mfma_f64_4x4x4f64(sUi4[s * 64 + lane], bt, o4, 0, 0, 0);
                 }
 #pragma unroll
-                for (int m = 0; m < MT; m++) {
+                for (int m = 0; m < MTF; m++) {
                     prev[c][m] = O[m];
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        if (16 * m + 4 * r < N) {
-                            const int row = 16 * m + 4 * r + g;
-                            dst[(size_t)(c * N + row) * 16 + p] = O[m][r];
-                            lmax = fmax(lmax, fabs(O[m][r]));
-                        }
+                        const int row = 16 * m + 4 * r + g;
+                        dst[(size_t)(c * N + row) * 16 + p] = O[m][r];
+                        lmax = fmax(lmax, fabs(O[m][r]));
                     }
+                }
+                if (TAIL4) {
+                    prevT[c] = o4;
+                    dst[(size_t)(c * N + 16 * MTF + g) * 16 + p] = o4;
+                    lmax = fmax(lmax, fabs(o4));
                 }
             }
             lmax = fmax(lmax, __shfl_xor(lmax, 16, 64));
@@ -394,15 +423,19 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
             if (__any(do_scale)) {
                 if (do_scale) {
 #pragma unroll
-                    for (int c = 0; c < C; c++)
+                    for (int c = 0; c < C; c++) {
 #pragma unroll
-                        for (int m = 0; m < MT; m++)
+                        for (int m = 0; m < MTF; m++)
 #pragma unroll
                             for (int r = 0; r < 4; r++) {
                                 prev[c][m][r] *= kScalingThresholdInv;
-                                if (16 * m + 4 * r < N)
-                                    dst[(size_t)(c * N + 16 * m + 4 * r + g) * 16 + p] = prev[c][m][r];
+                                dst[(size_t)(c * N + 16 * m + 4 * r + g) * 16 + p] = prev[c][m][r];
                             }
+                        if (TAIL4) {
+                            prevT[c] *= kScalingThresholdInv;
+                            dst[(size_t)(c * N + 16 * MTF + g) * 16 + p] = prevT[c];
+                        }
+                    }
                     sc += 1;
                     if (g == 0 && ptn < A.nptn) my_scale = kLogScalingThreshold * freq;
                 }
@@ -431,11 +464,17 @@ static hipError_t launch_trav_m(iqhip_engine *e, TravMArgs &A) {
     return hipGetLastError();
 }
 
+// LDS doubles of k_traverse_mfma2 that do not depend on the plan (A images, tail images, U^-1 transposed)
+int mfma2_fixed_lds_doubles(int n) {
+    const int mtf = n / 16, ks = n / 4;
+    return 2 * mtf * ks * 64 + ((n % 16) == 4 ? 2 * ks * 64 : 0) + (n * n * 8 <= 4096 ? n * n : 0);
+}
+
 template <int N, int C>
 static hipError_t launch_trav_m2(iqhip_engine *e, TravMArgs &A) {
-    constexpr int MT = (N + 15) / 16, KS = N / 4, WG = 256;
+    constexpr int KS = N / 4, WG = 256;
     const int nx = e->state_unknown + 1 - N;
-    const size_t lds = (size_t)(2 * MT * KS * 64 + nx * N + e->plan_lds_doubles) * sizeof(double);
+    const size_t lds = (size_t)(mfma2_fixed_lds_doubles(N) + nx * N + e->plan_lds_doubles) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma2<N, C, WG>),
