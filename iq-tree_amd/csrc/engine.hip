@@ -512,8 +512,11 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
             const int MT = (e->n + 15) / 16, KS = e->n / 4;
             const int fixed = (e->mfma_pipelined ? mfma2_fixed_lds_doubles(e->n) : 2 * MT * KS * 64) +
                               (e->state_unknown + 1 - e->n) * e->n;
-            // two workgroups per CU (160 KB LDS): <= 78 KB each, images included
-            budget = (78 * 1024) / 8 - fixed;
+            // two workgroups per CU (160 KB LDS): <= 78 KB each, images included (a third workgroup
+            // for the 20-state kernel was measured: no gain, more chunks); IQHIP_MFMA_LDS_KB overrides
+            int total_kb = 78;
+            if (const char *kb = getenv("IQHIP_MFMA_LDS_KB")) total_kb = atoi(kb);
+            budget = (total_kb * 1024) / 8 - fixed;
         } else {
             budget = (e->lds_budget_bytes / 8) - 128 - B;
         }
