@@ -29,7 +29,7 @@ $(LIBDIR)/libiqhost.so: $(HOST)/phylo_host.cpp $(HOST)/iqhost_c.cpp $(HOST)/phyl
 	    -L$(LIBDIR) -liqhip -Wl,-rpath,'$$ORIGIN'
 
 oracle/liblh_oracle.so: oracle/lh_oracle.c
-	$(CC) -O3 -mavx -ffp-contract=off -fPIC -shared -Wall -Wextra -o $@ $< -lm
+	$(CC) -O3 -mavx -fopenmp -ffp-contract=off -fPIC -shared -Wall -Wextra -o $@ $< -lm
 
 ref:
 	$(MAKE) -C oracle ref

@@ -32,6 +32,9 @@
 #include <stdint.h>
 #include <string.h>
 #include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define SCALING_THRESHOLD_INVER 0x1p256                  /* 2^256   phylotree.h:51 */
 #define SCALING_THRESHOLD 0x1p-256                       /* 2^-256  phylotree.h:52 */
@@ -55,6 +58,16 @@ static inline double dot4(const double *a, const double *b, int n) {
 double oracle_dot4(const double *a, const double *b, int n) { return dot4(a, b, n); }
 double oracle_exp(double x) { return exp(x); }
 double oracle_log(double x) { return log(x); }
+/* threads used by the pattern loop of oracle_partial_update (1 without OpenMP) */
+int oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
 double oracle_scaling_threshold(void) { return SCALING_THRESHOLD; }
 double oracle_log_scaling_threshold(void) { return LOG_SCALING_THRESHOLD; }
 
@@ -117,6 +130,87 @@ void oracle_tip_table(int n, int ncat, int state_unknown, const double *E,
     for (size_t x = 0; x < block; x++) table[state_unknown * block + x] = 1.0;
 }
 
+#ifdef __AVX__
+#include <immintrin.h>
+/* [sum(x0), sum(x1), sum(x2), sum(x3)] with each sum associated as (l0+l1)+(l2+l3): the same
+ * hadd/blend/permute combination the reference uses (phylokernel.h:31-43), so the 4-state fast path
+ * below is bit-identical to dot4(). */
+static inline __m256d hsum4(__m256d x0, __m256d x1, __m256d x2, __m256d x3) {
+    __m256d s01 = _mm256_hadd_pd(x0, x1);
+    __m256d s23 = _mm256_hadd_pd(x2, x3);
+    __m256d blend = _mm256_blend_pd(s01, s23, 12);
+    __m256d perm = _mm256_permute2f128_pd(s01, s23, 0x21);
+    return _mm256_add_pd(perm, blend);
+}
+/* E (4x4, row-major) times v (4) for one category -> 4 dot products */
+static inline __m256d mat4_vec(const double *E, __m256d v) {
+    return hsum4(_mm256_mul_pd(_mm256_loadu_pd(E), v), _mm256_mul_pd(_mm256_loadu_pd(E + 4), v),
+                 _mm256_mul_pd(_mm256_loadu_pd(E + 8), v), _mm256_mul_pd(_mm256_loadu_pd(E + 12), v));
+}
+#endif
+
+/* one pattern of the node update; returns its contribution to sum_scale */
+static inline double update_one_pattern(int n, int ncat, size_t block, size_t ptn, const double *EL,
+                                        const double *ER, const double *tabL, const double *tabR,
+                                        const uint8_t *left_states, const double *left_plh,
+                                        const short *left_scale, const uint8_t *right_states,
+                                        const double *right_plh, const short *right_scale,
+                                        const double *inv_evec, const double *ptn_freq,
+                                        const double *ptn_invar, double *tmp, double *out_plh,
+                                        short *out_scale) {
+    double sum_scale = 0.0;
+    {
+        double *out = out_plh + ptn * block;
+        const double *tl = left_states ? tabL + (size_t)left_states[ptn] * block : NULL;
+        const double *tr = right_states ? tabR + (size_t)right_states[ptn] * block : NULL;
+        const double *pl = left_states ? NULL : left_plh + ptn * block;
+        const double *pr = right_states ? NULL : right_plh + ptn * block;
+        double lh_max = 0.0;
+        /* scale_num init: TIP-TIP 0 (:247); TIP-INT copy of right (:290); INT-INT sum (:418) */
+        short sc = 0;
+        if (!left_states) sc = (short)(sc + left_scale[ptn]);
+        if (!right_states) sc = (short)(sc + right_scale[ptn]);
+#ifdef __AVX__
+        if (n == 4) { /* same arithmetic, 4 dot products per instruction group */
+            __m256d vmax = _mm256_setzero_pd();
+            const __m256d absmask = _mm256_castsi256_pd(_mm256_set1_epi64x(0x7fffffffffffffffLL));
+            for (int c = 0; c < ncat; c++) {
+                __m256d a = tl ? _mm256_loadu_pd(tl + c * 4) : mat4_vec(EL + c * 16, _mm256_loadu_pd(pl + c * 4));
+                __m256d b = tr ? _mm256_loadu_pd(tr + c * 4) : mat4_vec(ER + c * 16, _mm256_loadu_pd(pr + c * 4));
+                __m256d r = mat4_vec(inv_evec, _mm256_mul_pd(a, b));
+                _mm256_storeu_pd(out + c * 4, r);
+                vmax = _mm256_max_pd(vmax, _mm256_and_pd(r, absmask));
+            }
+            double m4[4];
+            _mm256_storeu_pd(m4, vmax);
+            lh_max = fmax(fmax(m4[0], m4[1]), fmax(m4[2], m4[3]));
+        } else
+#endif
+        for (int c = 0; c < ncat; c++) {
+            for (int x = 0; x < n; x++) {
+                double a = tl ? tl[c * n + x] : dot4(&EL[(size_t)c * n * n + x * n], &pl[c * n], n);
+                double b = tr ? tr[c * n + x] : dot4(&ER[(size_t)c * n * n + x * n], &pr[c * n], n);
+                tmp[x] = a * b;
+            }
+            for (int i = 0; i < n; i++) {
+                double r = dot4(tmp, &inv_evec[i * n], n);
+                out[c * n + i] = r;
+                double ar = fabs(r);
+                if (ar > lh_max) lh_max = ar;
+            }
+        }
+        /* the TIP-TIP case has no scaling check at all (phylokernel.h:246-281) */
+        if (!(left_states && right_states) &&
+            lh_max < SCALING_THRESHOLD && ptn_invar[ptn] == 0.0) {
+            for (size_t i = 0; i < block; i++) out[i] *= SCALING_THRESHOLD_INVER;
+            sum_scale += LOG_SCALING_THRESHOLD * ptn_freq[ptn];
+            sc = (short)(sc + 1);
+        }
+        out_scale[ptn] = sc;
+        }
+    return sum_scale;
+}
+
 /*
  * a7 / K3-K5, phylokernel.h:183-479.  One internal-node update in the reference's layout.
  * left_states/right_states != NULL marks a leaf child (one state byte per pattern,
@@ -149,39 +243,25 @@ double oracle_partial_update(int n, int ncat, size_t nptn,
         tabR = (double *)malloc(sizeof(double) * (state_unknown + 1) * block);
         oracle_tip_table(n, ncat, state_unknown, ER, tip, tabR);
     }
-    for (size_t ptn = 0; ptn < nptn; ptn++) {
-        double *out = out_plh + ptn * block;
-        const double *tl = left_states ? tabL + (size_t)left_states[ptn] * block : NULL;
-        const double *tr = right_states ? tabR + (size_t)right_states[ptn] * block : NULL;
-        const double *pl = left_states ? NULL : left_plh + ptn * block;
-        const double *pr = right_states ? NULL : right_plh + ptn * block;
-        double lh_max = 0.0;
-        /* scale_num init: TIP-TIP 0 (:247); TIP-INT copy of right (:290); INT-INT sum (:418) */
-        short sc = 0;
-        if (!left_states) sc = (short)(sc + left_scale[ptn]);
-        if (!right_states) sc = (short)(sc + right_scale[ptn]);
-        for (int c = 0; c < ncat; c++) {
-            for (int x = 0; x < n; x++) {
-                double a = tl ? tl[c * n + x] : dot4(&EL[(size_t)c * n * n + x * n], &pl[c * n], n);
-                double b = tr ? tr[c * n + x] : dot4(&ER[(size_t)c * n * n + x * n], &pr[c * n], n);
-                tmp[x] = a * b;
-            }
-            for (int i = 0; i < n; i++) {
-                double r = dot4(tmp, &inv_evec[i * n], n);
-                out[c * n + i] = r;
-                double ar = fabs(r);
-                if (ar > lh_max) lh_max = ar;
-            }
-        }
-        /* the TIP-TIP case has no scaling check at all (phylokernel.h:246-281) */
-        if (!(left_states && right_states) &&
-            lh_max < SCALING_THRESHOLD && ptn_invar[ptn] == 0.0) {
-            for (size_t i = 0; i < block; i++) out[i] *= SCALING_THRESHOLD_INVER;
-            sum_scale += LOG_SCALING_THRESHOLD * ptn_freq[ptn];
-            sc = (short)(sc + 1);
-        }
-        out_scale[ptn] = sc;
+    /* like the reference (phylokernel.h:251,335,410: "#pragma omp parallel for reduction(+: sum_scale)"
+     * over ptn); every pattern is independent */
+#ifdef _OPENMP
+#pragma omp parallel reduction(+ : sum_scale)
+    {
+        double *tmp_t = (double *)malloc(sizeof(double) * n);
+#pragma omp for schedule(static)
+        for (size_t ptn = 0; ptn < nptn; ptn++)
+            sum_scale += update_one_pattern(n, ncat, block, ptn, EL, ER, tabL, tabR, left_states, left_plh,
+                                            left_scale, right_states, right_plh, right_scale, inv_evec,
+                                            ptn_freq, ptn_invar, tmp_t, out_plh, out_scale);
+        free(tmp_t);
     }
+#else
+    for (size_t ptn = 0; ptn < nptn; ptn++)
+        sum_scale += update_one_pattern(n, ncat, block, ptn, EL, ER, tabL, tabR, left_states, left_plh,
+                                        left_scale, right_states, right_plh, right_scale, inv_evec, ptn_freq,
+                                        ptn_invar, tmp, out_plh, out_scale);
+#endif
     free(EL); free(ER); free(tmp); free(tabL); free(tabR);
     return sum_scale;
 }

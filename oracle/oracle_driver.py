@@ -21,7 +21,7 @@ def build():
     src = os.path.join(_HERE, "lh_oracle.c")
     out = os.path.join(_HERE, "liblh_oracle.so")
     if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O3", "-mavx", "-ffp-contract=off", "-fPIC", "-shared",
+        subprocess.check_call(["gcc", "-O3", "-mavx", "-fopenmp", "-ffp-contract=off", "-fPIC", "-shared",
                                "-o", out, src, "-lm"])
     return out
 
@@ -35,6 +35,8 @@ def lib():
     u8 = C.POINTER(C.c_uint8)
     sp = C.POINTER(C.c_short)
     L.oracle_scaling_threshold.restype = C.c_double
+    L.oracle_set_threads.argtypes = [C.c_int]
+    L.oracle_set_threads.restype = C.c_int
     L.oracle_log_scaling_threshold.restype = C.c_double
     L.oracle_tip_partial_lh.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp]
     L.oracle_tip_partial_lh.restype = None
@@ -240,8 +242,8 @@ class OracleTree:
             (l, ll), (r, rl) = (r, rl), (l, ll)
         args_l = self._child(to, l)
         args_r = self._child(to, r)
-        out = np.zeros((self.nptn, self.block))
-        sc = np.zeros(self.nptn, dtype=np.int16)
+        out = np.empty((self.nptn, self.block))
+        sc = np.empty(self.nptn, dtype=np.int16)
         sum_scale = self.L.oracle_partial_update(
             self.n, self.ncat, self.nptn, _dp(self.eval), _dp(self.evec), _dp(self.inv_evec),
             _dp(self.rates), _dp(self.tip), self.su,
