@@ -15,7 +15,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(_HERE, "lib")
+# IQHIP_LIB_DIR: alternative build directory (A/B timing of two builds on one GPU box)
+LIB_DIR = os.environ.get("IQHIP_LIB_DIR") or os.path.join(_HERE, "lib")
 REPO_ROOT = os.path.dirname(_HERE)
 
 # every symbol include/iqhip.h declares (kept in sync by tests/test_abi.py)
