@@ -13,7 +13,7 @@ HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-func
 HIP_SRCS   := $(CSRC)/engine.hip $(CSRC)/kernels_valu4.hip $(CSRC)/kernels_mfma.hip $(CSRC)/kernels_newton.hip
 HIP_OBJS   := $(patsubst $(CSRC)/%.hip,$(LIBDIR)/%.o,$(HIP_SRCS))
 
-all: $(LIBDIR)/libiqhip.so $(LIBDIR)/libiqhost.so oracle/liblh_oracle.so
+all: $(LIBDIR)/libiqhip.so $(LIBDIR)/libiqhost.so $(LIBDIR)/iqhip_lnl oracle/liblh_oracle.so
 
 $(LIBDIR):
 	mkdir -p $(LIBDIR)
@@ -24,9 +24,15 @@ $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/iqhip_internal.h include/iqhip.h | $(LIBDIR
 $(LIBDIR)/libiqhip.so: $(HIP_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS)
 
-$(LIBDIR)/libiqhost.so: $(HOST)/phylo_host.cpp $(HOST)/iqhost_c.cpp $(HOST)/phylo_host.h include/iqhip.h $(LIBDIR)/libiqhip.so
-	$(CXX) -O2 -std=c++17 -fPIC -shared -Wall -o $@ $(HOST)/phylo_host.cpp $(HOST)/iqhost_c.cpp \
-	    -L$(LIBDIR) -liqhip -Wl,-rpath,'$$ORIGIN'
+HOST_SRCS  := $(HOST)/phylo_host.cpp $(HOST)/iqhost_c.cpp $(HOST)/model_host.cpp $(HOST)/alignment_host.cpp $(HOST)/iqmodel_c.cpp
+HOST_HDRS  := $(HOST)/phylo_host.h $(HOST)/model_host.h $(HOST)/alignment_host.h include/iqhip.h
+
+$(LIBDIR)/libiqhost.so: $(HOST_SRCS) $(HOST_HDRS) $(LIBDIR)/libiqhip.so
+	$(CXX) -O2 -std=c++17 -fPIC -shared -Wall -o $@ $(HOST_SRCS) -L$(LIBDIR) -liqhip -Wl,-rpath,'$$ORIGIN'
+
+# stand-alone driver (the reference's "-s -te -m -blfix -n 0" evaluation) on top of the same libraries
+$(LIBDIR)/iqhip_lnl: cli/iqhip_lnl.cpp $(HOST_HDRS) $(LIBDIR)/libiqhost.so
+	$(CXX) -O2 -std=c++17 -Wall -o $@ cli/iqhip_lnl.cpp -L$(LIBDIR) -liqhost -liqhip -Wl,-rpath,'$$ORIGIN'
 
 oracle/liblh_oracle.so: oracle/lh_oracle.c
 	$(CC) -O3 -mavx -fopenmp -ffp-contract=off -fPIC -shared -Wall -Wextra -o $@ $< -lm

@@ -176,6 +176,33 @@ def libiqhost():
     lib.iqhost_num_partial_lh_computations.restype = C.c_long
     lib.iqhost_num_submissions.argtypes = [vp]
     lib.iqhost_num_submissions.restype = C.c_long
+    # model / alignment producers (iq-tree_amd/host/iqmodel_c.cpp)
+    ip, u8p = C.POINTER(C.c_int), C.POINTER(C.c_uint8)
+    lib.iqmodel_last_error.restype = C.c_char_p
+    lib.iqmodel_decompose.argtypes = [dp, dp, C.c_int, C.c_int, dp, dp, dp]
+    lib.iqmodel_gamma_rates.argtypes = [C.c_double, C.c_int, C.c_int, C.c_double, dp]
+    for f, n in (("iqmodel_ln_gamma", 1), ("iqmodel_incomplete_gamma", 2), ("iqmodel_point_normal", 1),
+                 ("iqmodel_point_chi2", 2)):
+        getattr(lib, f).argtypes = [C.c_double] * n
+        getattr(lib, f).restype = C.c_double
+    lib.iqmodel_genetic_code.argtypes = [C.c_int]
+    lib.iqmodel_genetic_code.restype = C.c_char_p
+    lib.iqaln_read.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_char_p]
+    lib.iqaln_destroy.argtypes = [vp]
+    lib.iqaln_destroy.restype = None
+    for f in ("iqaln_nseq", "iqaln_nsite", "iqaln_npattern", "iqaln_nstates", "iqaln_seq_type", "iqaln_state_unknown"):
+        getattr(lib, f).argtypes = [vp]
+    lib.iqaln_frac_const_sites.argtypes = [vp]
+    lib.iqaln_frac_const_sites.restype = C.c_double
+    lib.iqaln_seq_name.argtypes = [vp, C.c_int]
+    lib.iqaln_seq_name.restype = C.c_char_p
+    lib.iqaln_append_unobserved.argtypes = [vp, ip]
+    lib.iqaln_get.argtypes = [vp, u8p, dp, ip, ip]
+    lib.iqaln_ptn_invar.argtypes = [vp, C.c_double, dp, dp]
+    lib.iqaln_state_freq.argtypes = [vp, dp]
+    lib.iqaln_codon_freq.argtypes = [vp, C.c_int, dp, dp]
+    lib.iqaln_write_sitelh.argtypes = [vp, C.c_char_p, dp]
+    lib.iqmodel_build.argtypes = [vp, C.c_char_p, ip, dp, ip, dp, dp, dp, dp, dp, dp]
     lib._iq_typed = True
     return lib
 
@@ -429,3 +456,114 @@ class PhyloTree:
     @property
     def num_submissions(self):
         return self.lib.iqhost_num_submissions(self.h)
+
+
+# ---------------------------------------------------------------------------------------------
+# model / alignment producers: C++ in iq-tree_amd/host/{model,alignment}_host.cpp
+# ---------------------------------------------------------------------------------------------
+
+class AttrDict(dict):
+    """dict whose keys also read as attributes (so it can stand where a synth.Model is expected)."""
+    __getattr__ = dict.__getitem__
+
+
+def _mchk(lib, rc):
+    if rc != 0:
+        raise HostError(lib.iqmodel_last_error().decode())
+
+
+def decompose_rate_matrix(rate_matrix, state_freq, ignore_state_freq=False):
+    """ModelGTR::decomposeRateMatrix -> dict(eval, evec, inv_evec) (row-major, reference layout)."""
+    lib = libiqhost()
+    r = np.ascontiguousarray(rate_matrix, dtype=np.float64)
+    f = np.ascontiguousarray(state_freq, dtype=np.float64)
+    n = f.size
+    ev, U, Ui = np.zeros(n), np.zeros((n, n)), np.zeros((n, n))
+    _mchk(lib, lib.iqmodel_decompose(_dptr(r), _dptr(f), n, int(ignore_state_freq), _dptr(ev), _dptr(U), _dptr(Ui)))
+    return AttrDict(eval=ev, evec=U, inv_evec=Ui)
+
+
+def gamma_rates(shape, ncat, median=False, p_invar=0.0):
+    """RateGamma::computeRates."""
+    lib = libiqhost()
+    out = np.zeros(ncat)
+    _mchk(lib, lib.iqmodel_gamma_rates(float(shape), int(ncat), int(median), float(p_invar), _dptr(out)))
+    return out
+
+
+class Alignment:
+    """iqhost::Alignment: PHYLIP/FASTA reader + site->pattern compression."""
+
+    def __init__(self, filename=None, content=None, seq_type=""):
+        self.lib = libiqhost()
+        self.h = C.c_void_p()
+        rc = self.lib.iqaln_read(C.byref(self.h), filename.encode() if filename else None,
+                                 content.encode() if content is not None else None, seq_type.encode())
+        _mchk(self.lib, rc)
+        self.n_unobserved = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.iqaln_destroy(self.h)
+            self.h = None
+
+    nseq = property(lambda s: s.lib.iqaln_nseq(s.h))
+    nsite = property(lambda s: s.lib.iqaln_nsite(s.h))
+    npattern = property(lambda s: s.lib.iqaln_npattern(s.h))
+    nstates = property(lambda s: s.lib.iqaln_nstates(s.h))
+    seq_type = property(lambda s: s.lib.iqaln_seq_type(s.h))
+    state_unknown = property(lambda s: s.lib.iqaln_state_unknown(s.h))
+    frac_const_sites = property(lambda s: s.lib.iqaln_frac_const_sites(s.h))
+
+    @property
+    def seq_names(self):
+        return [self.lib.iqaln_seq_name(self.h, i).decode() for i in range(self.nseq)]
+
+    def append_unobserved_const_patterns(self):
+        n = C.c_int()
+        _mchk(self.lib, self.lib.iqaln_append_unobserved(self.h, C.byref(n)))
+        self.n_unobserved = n.value
+        return n.value
+
+    def arrays(self):
+        """-> states[nseq, nptn] uint8, ptn_freq[nptn], site_pattern[nsite], const_char[nptn] (-1 = not constant)"""
+        ns, npt, nsite = self.nseq, self.npattern, self.nsite
+        st = np.zeros((ns, npt), dtype=np.uint8)
+        fr = np.zeros(npt)
+        sp = np.zeros(nsite, dtype=np.int32)
+        cc = np.zeros(npt, dtype=np.int32)
+        _mchk(self.lib, self.lib.iqaln_get(self.h, st.ctypes.data_as(C.POINTER(C.c_uint8)), _dptr(fr),
+                                           sp.ctypes.data_as(C.POINTER(C.c_int)), cc.ctypes.data_as(C.POINTER(C.c_int))))
+        return st, fr, sp, cc
+
+    def ptn_invar(self, p_invar, state_freq):
+        out = np.zeros(self.npattern)
+        f = np.ascontiguousarray(state_freq, dtype=np.float64)
+        _mchk(self.lib, self.lib.iqaln_ptn_invar(self.h, float(p_invar), _dptr(f), _dptr(out)))
+        return out
+
+    def state_freq(self):
+        out = np.zeros(self.nstates)
+        _mchk(self.lib, self.lib.iqaln_state_freq(self.h, _dptr(out)))
+        return out
+
+    def codon_freq(self, f3x4=False):
+        out, nt = np.zeros(self.nstates), np.zeros(12)
+        _mchk(self.lib, self.lib.iqaln_codon_freq(self.h, int(f3x4), _dptr(out), _dptr(nt)))
+        return out, nt
+
+    def write_sitelh(self, filename, pattern_lh):
+        p = np.ascontiguousarray(pattern_lh, dtype=np.float64)
+        _mchk(self.lib, self.lib.iqaln_write_sitelh(self.h, filename.encode(), _dptr(p)))
+
+    def build_model(self, model_string):
+        """-m string -> the dict PhyloTree.set_model() takes (+ state_freq, p_invar, asc)."""
+        n = self.nstates
+        ncat, asc, pinv = C.c_int(), C.c_int(), C.c_double()
+        ev, U, Ui, fr = np.zeros(n), np.zeros((n, n)), np.zeros((n, n)), np.zeros(n)
+        rates, props = np.zeros(64), np.zeros(64)
+        _mchk(self.lib, self.lib.iqmodel_build(self.h, model_string.encode(), C.byref(ncat), C.byref(pinv), C.byref(asc),
+                                               _dptr(ev), _dptr(U), _dptr(Ui), _dptr(fr), _dptr(rates), _dptr(props)))
+        k = ncat.value
+        return AttrDict(nstates=n, ncat=k, eval=ev, evec=U, inv_evec=Ui, state_freq=fr, rates=rates[:k].copy(),
+                    props=props[:k].copy(), p_invar=pinv.value, asc=bool(asc.value))

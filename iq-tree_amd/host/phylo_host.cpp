@@ -203,7 +203,8 @@ void PhyloTree::readTreeString(const std::string &newick, const std::vector<std:
 
 static void writeNewick(std::ostringstream &os, const PhyloNode *node, const PhyloNode *dad) {
     if (node->isLeaf() && dad) {
-        os << node->id;
+        if (node->name.empty()) os << node->id;  // leaf labels as read (MTree::printTree writes names)
+        else os << node->name;
         return;
     }
     os << "(";

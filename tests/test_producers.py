@@ -1,0 +1,269 @@
+"""Model / alignment producers in C++ (iq-tree_amd/host/model_host.cpp, alignment_host.cpp).
+CPU-only: the producers are host code.  They are checked against scipy (exact Gamma quantiles / means,
+expm), against the test-suite's own Python reader, and against facts the survey recorded from the
+reference (example.phy: 44 sequences x 384 sites -> 355 patterns)."""
+import os
+
+import numpy as np
+import pytest
+from scipy import special, stats
+from scipy.linalg import expm
+
+from phylip import read_phylip_dna
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EXAMPLE = os.path.join(HERE, "golden", "example.phy")
+
+
+# ---------------------------------------------------------------- discrete Gamma --------------
+def test_gamma_helpers_against_scipy(pkg):
+    lib = pkg.libiqhost()
+    for a in (0.05, 0.3, 0.9, 1.0, 2.5, 7.0, 33.0):
+        assert abs(lib.iqmodel_ln_gamma(a) - special.gammaln(a)) < 2e-9 * max(1.0, abs(special.gammaln(a)))
+        for x in (0.01, 0.5, 1.0, 3.0, 20.0):
+            assert abs(lib.iqmodel_incomplete_gamma(x, a) - special.gammainc(a, x)) < 2e-7
+    for p in (0.001, 0.05, 0.25, 0.5, 0.75, 0.999):
+        assert abs(lib.iqmodel_point_normal(p) - stats.norm.ppf(p)) < 5e-4      # AS 70: ~7 digits mid-range, 1e-4 tails
+        for v in (0.1, 0.6, 1.8, 4.0, 50.0):
+            exact = stats.chi2.ppf(p, v)
+            assert abs(lib.iqmodel_point_chi2(p, v) - exact) < 5e-6 * max(exact, 1e-3), (p, v)
+    assert lib.iqmodel_point_chi2(1e-7, 2.0) == -1.0 and lib.iqmodel_point_chi2(0.5, 0.0) == -1.0   # error returns
+
+
+@pytest.mark.parametrize("alpha", [0.05, 0.2, 0.5, 0.9, 0.934, 1.0, 2.0, 10.0, 50.0])
+@pytest.mark.parametrize("ncat", [2, 4, 8])
+def test_gamma_rates_mean(pkg, synth, alpha, ncat):
+    r = pkg.gamma_rates(alpha, ncat)
+    exact = synth.discrete_gamma_rates(alpha, ncat)          # scipy quantiles + exact means
+    assert np.all(np.diff(r) > 0)
+    assert abs(r.mean() - 1.0) < 1e-6                        # AS 32 is truncated at 1e-8
+    assert np.max(np.abs(r - exact)) < 2e-5 * max(1.0, exact.max())
+
+
+def test_gamma_rates_median_and_invar(pkg):
+    alpha, ncat = 0.7, 4
+    r = pkg.gamma_rates(alpha, ncat, median=True)
+    q = stats.gamma.ppf((2 * np.arange(ncat) + 1) / (2.0 * ncat), a=alpha, scale=1.0 / alpha)
+    assert np.allclose(r, q / q.mean(), rtol=2e-5)
+    assert abs(r.mean() - 1.0) < 1e-12
+    assert np.allclose(pkg.gamma_rates(alpha, ncat, p_invar=0.2), pkg.gamma_rates(alpha, ncat) / 0.8, rtol=1e-15)
+    assert pkg.gamma_rates(3.0, 1, p_invar=0.3)[0] == 1.0     # ncategory == 1 returns before the division
+
+
+# ---------------------------------------------------------------- eigen-systems ---------------
+def _check_eigensystem(es, Q, tol=1e-11):
+    n = len(es["eval"])
+    U, Ui, lam = es["evec"], es["inv_evec"], es["eval"]
+    assert np.max(np.abs(U @ Ui - np.eye(n))) < tol
+    assert np.max(np.abs(U @ np.diag(lam) @ Ui - Q)) < tol * max(1.0, np.abs(Q).max())
+    for t in (0.01, 0.3, 2.0):
+        assert np.max(np.abs(U @ np.diag(np.exp(lam * t)) @ Ui - expm(Q * t))) < 1e-10
+
+
+def test_decompose_gtr_matches_numpy_model(pkg, synth):
+    m = synth.gtr_model()
+    R = np.array([[0, 1.5, 2.4, 1.8], [1.5, 0, 1.9, 2.8], [2.4, 1.9, 0, 1.0], [1.8, 2.8, 1.0, 0]])
+    es = pkg.decompose_rate_matrix(R, [0.25, 0.26, 0.25, 0.24])
+    _check_eigensystem(es, m.Q)
+    assert np.allclose(np.sort(es["eval"]), np.sort(m.eval), atol=1e-13)
+    assert abs(-(np.array([0.25, 0.26, 0.25, 0.24]) * np.diag(m.Q)).sum() - 1.0) < 1e-14   # one substitution per unit time
+
+
+@pytest.mark.parametrize("n", [20, 64])
+def test_decompose_large_random(pkg, synth, n):
+    m = synth.random_reversible_model(n, seed=5)
+    rng = np.random.default_rng(5)
+    R = rng.gamma(shape=1.0, scale=1.0, size=(n, n)) + 0.05
+    R = (R + R.T) / 2
+    es = pkg.decompose_rate_matrix(R, m.freqs * 3.0)      # un-normalised frequencies are normalised (:191-197)
+    _check_eigensystem(es, m.Q, tol=5e-11)
+
+
+def test_decompose_drops_zero_frequency_states(pkg):
+    R = np.ones((5, 5))
+    f = np.array([0.3, 0.0, 0.2, 0.5, 0.0])
+    es = pkg.decompose_rate_matrix(R, f)
+    U, Ui, lam = es["evec"], es["inv_evec"], es["eval"]
+    for z in (1, 4):                                       # eigendecomposition.cpp:232-246: identity rows, eigenvalue 0
+        assert lam[z] == 0.0
+        assert np.array_equal(U[z], np.eye(5)[z]) and np.array_equal(Ui[z], np.eye(5)[z])
+        assert np.array_equal(U[:, z], np.eye(5)[z]) and np.array_equal(Ui[:, z], np.eye(5)[z])
+    keep = [0, 2, 3]
+    fk = f[keep]
+    Q = np.ones((3, 3)) * fk[None, :]
+    np.fill_diagonal(Q, 0)
+    np.fill_diagonal(Q, -Q.sum(1))
+    Q /= -(fk * np.diag(Q)).sum()
+    sub = dict(eval=lam[keep], evec=U[np.ix_(keep, keep)], inv_evec=Ui[np.ix_(keep, keep)])
+    _check_eigensystem(sub, Q)
+
+
+# ---------------------------------------------------------------- alignments ------------------
+def test_example_phy_matches_survey_and_python_reader(pkg, synth):
+    aln = pkg.Alignment(EXAMPLE)
+    assert (aln.nseq, aln.nsite, aln.npattern, aln.nstates, aln.state_unknown) == (44, 384, 355, 4, 18)
+    names, rows = read_phylip_dna(EXAMPLE)
+    assert aln.seq_names == names
+    st, fr, sp, cc = aln.arrays()
+    assert fr.sum() == 384 and np.array_equal(st[:, sp], rows)          # site -> pattern round trip
+    pat, freq = synth.compress_patterns(rows)
+    # same multiset of patterns; the C++ order is first appearance (alignment.cpp:674-700)
+    assert sorted(map(bytes, st.T)) == sorted(map(bytes, pat.T))
+    first_seen = []
+    seen = set()
+    for s in range(rows.shape[1]):
+        b = bytes(rows[:, s])
+        if b not in seen:
+            seen.add(b)
+            first_seen.append(b)
+    assert [bytes(c) for c in st.T] == first_seen
+
+
+PHY_INTERLEAVED = """ 4 12
+alpha      ACGTAC
+beta       ACGTAC
+gamma      ACG-AC
+delta      ACGTRC
+
+GTTTNA
+GTTTTA
+GTTT?A
+GTTTTA
+"""
+
+
+def test_interleaved_phylip_fasta_and_const_patterns(pkg):
+    a = pkg.Alignment(content=PHY_INTERLEAVED)
+    fasta = ">alpha x\nACGTACGTTTNA\n>beta\nACGTAC\nGTTTTA\n>gamma\nACG-ACGTTT?A\n>delta\nacgtrcGTTTTA\n"
+    b = pkg.Alignment(content=fasta)
+    assert a.seq_names == b.seq_names == ["alpha", "beta", "gamma", "delta"]
+    sa, fa, spa, cca = a.arrays()
+    sb, fb, spb, ccb = b.arrays()
+    assert np.array_equal(sa, sb) and np.array_equal(fa, fb) and np.array_equal(spa, spb)
+    assert a.nsite == 12 and a.npattern == 7
+    # columns: A C G [T T - T] [A A A R] C G T T T [N T ? T] A -> constant incl. gaps / compatible ambiguity
+    site_const = [cca[p] for p in spa]
+    assert site_const == [0, 1, 2, 3, 0, 1, 2, 3, 3, 3, 3, 0]
+    assert a.frac_const_sites == 1.0
+    inv = a.ptn_invar(0.2, [0.1, 0.2, 0.3, 0.4])
+    assert np.allclose(inv[spa], 0.2 * np.array([0.1, 0.2, 0.3, 0.4])[site_const])
+
+
+def test_alignment_errors(pkg):
+    with pytest.raises(pkg.HostError, match="at least 3 sequences"):
+        pkg.Alignment(content=" 2 4\na ACGT\nb ACGT\n")
+    with pytest.raises(pkg.HostError, match="Unrecognized character"):
+        pkg.Alignment(content=" 3 4\na ACGT\nb AC!T\nc ACGT\n")
+    with pytest.raises(pkg.HostError, match="duplicated"):
+        pkg.Alignment(content=" 3 4\na ACGT\na ACGT\nc ACGT\n")
+    with pytest.raises(pkg.HostError, match="not enough|wrong sequence length"):
+        pkg.Alignment(content=" 3 4\na ACGT\nb ACG\nc ACGT\n")
+    with pytest.raises(pkg.HostError, match="invalid character"):
+        pkg.Alignment(content=" 3 4\na ACGT\nb ACJT\nc ACGT\n", seq_type="DNA")
+    with pytest.raises(pkg.HostError, match="multiple of 3"):
+        pkg.Alignment(content=" 3 4\na ACGT\nb ACGT\nc ACGT\n", seq_type="CODON")
+
+
+def test_protein_and_codon_encoding(pkg):
+    prot = pkg.Alignment(content=" 3 8\ns1 ARNDBZJX\ns2 ARND-*UV\ns3 ARNDCQEG\n")
+    assert (prot.nstates, prot.state_unknown, prot.seq_type) == (20, 23, pkg.SEQ_PROTEIN)
+    st, _, sp, _ = prot.arrays()
+    assert st[:, sp][0].tolist() == [0, 1, 2, 3, 20, 21, 22, 23]
+    assert st[:, sp][1].tolist() == [0, 1, 2, 3, 23, 23, 23, 19]
+    cod = pkg.Alignment(content=" 3 12\ns1 ATGAAATTTGGG\ns2 ATGAARTTT---\ns3 ATGAAGTTCGGN\n", seq_type="CODON")
+    assert (cod.nstates, cod.state_unknown, cod.nsite) == (64, 64, 4)
+    st, _, sp, _ = cod.arrays()
+    # ATG = 0*16+3*4+2 = 14, AAA = 0, TTT = 63, GGG = 42, AAG = 2, TTC = 61
+    assert st[:, sp].tolist() == [[14, 0, 63, 42], [14, 64, 63, 64], [14, 2, 61, 64]]
+    with pytest.raises(pkg.HostError, match="stop codon"):
+        pkg.Alignment(content=" 3 3\ns1 TAA\ns2 ATG\ns3 ATG\n", seq_type="CODON")
+
+
+def test_genetic_code_standard(pkg):
+    code = pkg.libiqhost().iqmodel_genetic_code(1).decode()
+    idx = {"A": 0, "C": 1, "G": 2, "T": 3}
+    cod = lambda s: 16 * idx[s[0]] + 4 * idx[s[1]] + idx[s[2]]
+    assert len(code) == 64 and code.count("*") == 3
+    assert all(code[cod(c)] == "*" for c in ("TAA", "TAG", "TGA"))
+    for c, aa in (("ATG", "M"), ("TGG", "W"), ("AAA", "K"), ("GGG", "G"), ("TTT", "F"), ("CTG", "L"), ("AGC", "S"),
+                  ("CAT", "H"), ("GAT", "D"), ("TGC", "C"), ("ATA", "I"), ("CGA", "R")):
+        assert code[cod(c)] == aa
+    assert pkg.libiqhost().iqmodel_genetic_code(2).decode()[cod("TGA")] == "W"     # vertebrate mitochondrial
+
+
+def test_unobserved_const_patterns(pkg):
+    var = " 4 3\na ACG\nb CCT\nc AGG\nd ATT\n"
+    a = pkg.Alignment(content=var)
+    assert a.append_unobserved_const_patterns() == 4
+    st, fr, _, cc = a.arrays()
+    assert st[:, -4:].T.tolist() == [[0] * 4, [1] * 4, [2] * 4, [3] * 4] and fr[-4:].tolist() == [0, 0, 0, 0]
+    assert cc[-4:].tolist() == [0, 1, 2, 3]
+    with pytest.raises(pkg.HostError, match="constant patterns are observed"):
+        pkg.Alignment(content=" 4 3\na ACG\nb ACT\nc AGG\nd ATT\n").append_unobserved_const_patterns()
+
+
+# ---------------------------------------------------------------- -m strings ------------------
+def test_model_string_gtr_gamma_invar(pkg, synth):
+    aln = pkg.Alignment(EXAMPLE)
+    m = aln.build_model("GTR{1.513,2.393,1.769,1.912,2.838}+F{0.249,0.262,0.251,0.238}+I{0.1}+G4{0.934}")
+    ref = synth.gtr_model((1.513, 2.393, 1.769, 1.912, 2.838, 1.0), (0.249, 0.262, 0.251, 0.238), 0.934, 4, 0.1)
+    assert m["ncat"] == 4 and m["p_invar"] == 0.1 and not m["asc"]
+    assert np.allclose(m["rates"], ref.rates, rtol=3e-5) and np.allclose(m["props"], ref.props, rtol=1e-15)
+    _check_eigensystem(m, ref.Q)
+    assert np.allclose(m["rates"], pkg.gamma_rates(0.934, 4, p_invar=0.1), rtol=0, atol=0)
+
+
+def test_model_string_families(pkg):
+    aln = pkg.Alignment(EXAMPLE)
+    jc = aln.build_model("JC")
+    assert jc["ncat"] == 1 and np.allclose(jc["state_freq"], 0.25) and np.allclose(np.sort(jc["eval"]), [-4 / 3] * 3 + [0])
+    emp = aln.state_freq()
+    assert abs(emp.sum() - 1) < 1e-12 and np.all(emp > 0.15)
+    hky = aln.build_model("HKY{2.5}+G4{0.5}")
+    assert np.allclose(hky["state_freq"], emp)
+    k80 = aln.build_model("K80{2.5}")
+    P = k80["evec"] @ np.diag(np.exp(k80["eval"] * 0.1)) @ k80["inv_evec"]
+    assert abs(P[0, 2] / P[0, 1] - 2.5) < 0.2 and abs(P[0, 1] - P[0, 3]) < 1e-15       # transitions A<->G faster
+    inv = aln.build_model("F81+I{0.25}")
+    assert inv["ncat"] == 1 and inv["rates"][0] == 1 / 0.75 and inv["props"][0] == 0.75
+    for bad in ("GTR{1,2}", "FOO", "GTR{1,2,3,4,5}+G4", "HKY{2}+Q", "JC+I{1.5}"):
+        with pytest.raises(pkg.HostError):
+            aln.build_model(bad)
+
+
+def test_codon_model_gy(pkg):
+    rng = np.random.default_rng(3)
+    code = pkg.libiqhost().iqmodel_genetic_code(1).decode()
+    sense = [i for i in range(64) if code[i] != "*"]
+    nuc = "ACGT"
+    seqs = ["".join(nuc[c // 16] + nuc[(c % 16) // 4] + nuc[c % 4] for c in rng.choice(sense, 40)) for _ in range(5)]
+    aln = pkg.Alignment(content=" 5 120\n" + "".join("t%d %s\n" % (i, s) for i, s in enumerate(seqs)), seq_type="CODON")
+    m = aln.build_model("GY{2.0,0.3}+F1X4")
+    f, nt = aln.codon_freq(False)
+    assert np.allclose(m["state_freq"], f / f.sum()) and abs(nt[:4].sum() - 1) < 1e-12
+    stops = [i for i in range(64) if code[i] == "*"]
+    assert np.allclose(f[stops], 1e-4)
+    U, Ui, lam = m["evec"], m["inv_evec"], m["eval"]
+    P = U @ np.diag(np.exp(lam * 0.5)) @ Ui
+    assert np.allclose(P.sum(1), 1.0, atol=1e-10) and P.min() > -1e-12
+    for s in stops:                                           # stop codons are isolated states
+        assert abs(P[s, s] - 1) < 1e-10
+    Q = U @ np.diag(lam) @ Ui
+    cod = lambda s: 16 * nuc.index(s[0]) + 4 * nuc.index(s[1]) + nuc.index(s[2])
+    pi = m["state_freq"]
+    # TTT->TTC synonymous transition; TTT->TTA nonsynonymous transversion; TTT->GGG multi-nucleotide
+    r_syn_ts = Q[cod("TTT"), cod("TTC")] / pi[cod("TTC")]
+    r_non_tv = Q[cod("TTT"), cod("TTA")] / pi[cod("TTA")]
+    assert abs(r_syn_ts / r_non_tv - 2.0 / 0.3) < 1e-8 and abs(Q[cod("TTT"), cod("GGG")]) < 1e-12
+    assert abs(-(pi * np.diag(Q)).sum() - 1.0) < 1e-10
+
+
+def test_sitelh_writer(pkg, tmp_path):
+    a = pkg.Alignment(content=PHY_INTERLEAVED)
+    _, _, sp, _ = a.arrays()
+    lh = -np.arange(1, a.npattern + 1, dtype=np.float64) * 1.5
+    out = tmp_path / "x.sitelh"
+    a.write_sitelh(str(out), lh)
+    lines = out.read_text().splitlines()
+    assert lines[0] == "1 12" and lines[1].startswith("Site_Lh   ")
+    assert np.allclose([float(x) for x in lines[1].split()[1:]], lh[sp])
