@@ -10,7 +10,7 @@ CSRC       := $(PKG)/csrc
 HOST       := $(PKG)/host
 LIBDIR     := $(PKG)/lib
 HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result
-HIP_SRCS   := $(CSRC)/engine.hip $(CSRC)/kernels_valu4.hip $(CSRC)/kernels_mfma.hip $(CSRC)/kernels_newton.hip
+HIP_SRCS   := $(CSRC)/engine.hip $(CSRC)/kernels_valu4.hip $(CSRC)/kernels_mfma.hip $(CSRC)/kernels_newton.hip $(CSRC)/kernels_rell.hip
 HIP_OBJS   := $(patsubst $(CSRC)/%.hip,$(LIBDIR)/%.o,$(HIP_SRCS))
 
 all: $(LIBDIR)/libiqhip.so $(LIBDIR)/libiqhost.so $(LIBDIR)/iqhip_lnl oracle/liblh_oracle.so

@@ -183,6 +183,18 @@ int iqhip_fetch_scale_num(iqhip_engine *e, uint64_t key, int16_t *out /* nptn */
 int iqhip_fetch_pattern_lh(iqhip_engine *e, double *out /* nptn */);
 int iqhip_fetch_partial(iqhip_engine *e, uint64_t key, double *out /* nptn*block, ref layout */);
 int iqhip_fetch_theta(iqhip_engine *e, double *out /* nptn*block, ref layout */);
+/* Consumers of the device-resident _pattern_lh (so -wsl / UFBoot need no full-vector round trip per tree).
+ * iqhip_fetch_pattern_lh_scaled: PhyloTree::computePatternLikelihood (phylotree.cpp:1200-1230) for the
+ *   branch (a,b) the last lnL evaluation ran on: _pattern_lh + (scale_num_a + scale_num_b)*log(2^-256).
+ * iqhip_set_boot_samples: UFBoot's boot_samples (iqtree.h:670, BootValType = float), [nsamples][nptn],
+ *   uploaded once.  iqhip_rell: the RELL scores of IQTree::saveCurrentTree (iqtree.cpp:2726-2736),
+ *   rell[s] = dotProduct(pattern_lh, boot_samples[s]) (phylokernel.h:55-61), accumulated in double.
+ *   The _async form leaves the scores in the result vector [0, nsamples) for a sharded caller to
+ *   all-reduce before iqhip_result_read. */
+int iqhip_fetch_pattern_lh_scaled(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b, double *out /* nptn */);
+int iqhip_set_boot_samples(iqhip_engine *e, const float *samples, int nsamples);
+int iqhip_rell(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b, double *rell /* nsamples */);
+int iqhip_rell_async(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b);
 /* Host -> device (tests; SPR/NNI code that fills a buffer on the host). */
 int iqhip_upload_partial(iqhip_engine *e, uint64_t key, const double *partial_lh,
                          const int16_t *scale_num);

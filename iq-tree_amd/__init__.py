@@ -29,6 +29,7 @@ IQHIP_SYMBOLS = [
     "iqhip_result_capacity", "iqhip_traverse_lnl_async", "iqhip_derv_async", "iqhip_result_read",
     "iqhip_synchronize", "iqhip_fetch_scale_num", "iqhip_fetch_pattern_lh", "iqhip_fetch_partial",
     "iqhip_fetch_theta", "iqhip_upload_partial", "iqhip_timing_enable", "iqhip_timing_read",
+    "iqhip_fetch_pattern_lh_scaled", "iqhip_set_boot_samples", "iqhip_rell", "iqhip_rell_async",
 ]
 
 
@@ -116,6 +117,10 @@ def libiqhip():
     lib.iqhip_fetch_partial.argtypes = [vp, C.c_uint64, dp]
     lib.iqhip_fetch_theta.argtypes = [vp, dp]
     lib.iqhip_upload_partial.argtypes = [vp, C.c_uint64, dp, ip]
+    lib.iqhip_fetch_pattern_lh_scaled.argtypes = [vp, BranchEnd, BranchEnd, dp]
+    lib.iqhip_set_boot_samples.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
+    lib.iqhip_rell.argtypes = [vp, BranchEnd, BranchEnd, dp]
+    lib.iqhip_rell_async.argtypes = [vp, BranchEnd, BranchEnd]
     lib.iqhip_timing_enable.argtypes = [vp, C.c_int]
     lib.iqhip_timing_read.argtypes = [vp, dp, C.POINTER(C.c_int64), C.c_int]
     lib._iq_typed = True
@@ -171,6 +176,9 @@ def libiqhost():
     lib.iqhost_fetch_scale_num.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int16)]
     lib.iqhost_fetch_partial.argtypes = [vp, C.c_int, C.c_int, dp]
     lib.iqhost_fetch_pattern_lh.argtypes = [vp, dp]
+    lib.iqhost_compute_pattern_likelihood.argtypes = [vp, dp]
+    lib.iqhost_set_boot_samples.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
+    lib.iqhost_compute_rell.argtypes = [vp, dp, C.c_int]
     lib.iqhost_last_plan.argtypes = [vp, C.POINTER(C.c_int), dp, C.POINTER(C.c_uint64), C.c_int]
     lib.iqhost_num_partial_lh_computations.argtypes = [vp]
     lib.iqhost_num_partial_lh_computations.restype = C.c_long
@@ -433,6 +441,24 @@ class PhyloTree:
     def fetch_pattern_lh(self):
         out = np.zeros(self.nptn)
         self._chk(self.lib.iqhost_fetch_pattern_lh(self.h, _dptr(out)))
+        return out
+
+    def compute_pattern_likelihood(self):
+        """PhyloTree::computePatternLikelihood: per-pattern lnL with the scaling events put back."""
+        out = np.zeros(self.nptn)
+        self._chk(self.lib.iqhost_compute_pattern_likelihood(self.h, _dptr(out)))
+        return out
+
+    def set_boot_samples(self, samples):
+        """UFBoot boot_samples: float32 [nsamples, nptn] pattern weights, uploaded once."""
+        s = np.ascontiguousarray(samples, dtype=np.float32)
+        assert s.ndim == 2 and s.shape[1] == self.nptn
+        self._nboot = s.shape[0]
+        self._chk(self.lib.iqhost_set_boot_samples(self.h, s.ctypes.data_as(C.POINTER(C.c_float)), s.shape[0]))
+
+    def compute_rell(self):
+        out = np.zeros(self._nboot)
+        self._chk(self.lib.iqhost_compute_rell(self.h, _dptr(out), out.size))
         return out
 
     def last_plan(self):

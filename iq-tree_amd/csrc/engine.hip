@@ -147,7 +147,7 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
     void *ptrs[] = {e->d_states, e->d_freq, e->d_invar, e->d_eval, e->d_evec, e->d_inv_evec,
                     e->d_rates, e->d_props, e->d_tip, e->d_ops, e->d_slab,
                     e->d_theta, e->d_pattern_lh, e->dummy.plh, e->dummy.sc, e->d_newton_partials,
-                    e->d_newton_barrier};
+                    e->d_newton_barrier, e->d_ptn_scaled, e->d_boot};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (e->h_ops) hipHostFree(e->h_ops);
@@ -927,6 +927,71 @@ extern "C" int iqhip_fetch_pattern_lh(iqhip_engine *e, double *out) {
         for (int64_t p = 0; p < nobs; p++) out[p] -= e->pattern_lh_shift;
         for (int64_t p = nobs; p < e->nptn; p++) out[p] = 0.0;
     }
+    return IQHIP_OK;
+}
+
+// ---- consumers of the device-resident pattern lnL (kernels_rell.hip) ---------------------------
+static int scaled_pattern_lh(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b) {
+    const int16_t *sc[2] = {nullptr, nullptr};
+    const iqhip_branch_end ends[2] = {a, b};
+    for (int k = 0; k < 2; k++) {
+        if (ends[k].leaf >= 0) continue;  // leaves carry no scaling events
+        int idx;
+        int rc = slab_for_key(e, ends[k].key, false, &idx);
+        if (rc) return rc;
+        sc[k] = e->slabs[idx].sc;
+    }
+    if (!e->d_ptn_scaled) HIPCHK(hipMalloc((void **)&e->d_ptn_scaled, sizeof(double) * (size_t)e->nptn_pad));
+    HIPCHK(launch_pattern_lh_scaled(e, sc[0], sc[1], e->d_ptn_scaled));
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_fetch_pattern_lh_scaled(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b, double *out) {
+    if (!e || !out) return fail(IQHIP_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->device));
+    int rc = scaled_pattern_lh(e, a, b);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, e->d_ptn_scaled, sizeof(double) * (size_t)e->nptn, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_set_boot_samples(iqhip_engine *e, const float *samples, int nsamples) {
+    if (!e || (nsamples > 0 && !samples) || nsamples < 0) return fail(IQHIP_ERR_INVALID, "bad bootstrap samples");
+    if (nsamples > 16384) return fail(IQHIP_ERR_INVALID, "at most 16384 bootstrap samples");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->d_boot) HIPCHK(hipFree(e->d_boot));
+    e->d_boot = nullptr;
+    e->nboot = 0;
+    if (nsamples == 0) return IQHIP_OK;
+    const size_t pitch = (size_t)e->nptn_pad;
+    HIPCHK(hipMalloc((void **)&e->d_boot, sizeof(float) * pitch * nsamples));
+    HIPCHK(hipMemset(e->d_boot, 0, sizeof(float) * pitch * nsamples));
+    HIPCHK(hipMemcpy2D(e->d_boot, pitch * sizeof(float), samples, (size_t)e->nptn * sizeof(float),
+                       (size_t)e->nptn * sizeof(float), nsamples, hipMemcpyHostToDevice));
+    e->nboot = nsamples;
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_rell_async(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b) {
+    if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    if (e->nboot == 0) return fail(IQHIP_ERR_INVALID, "no bootstrap samples (iqhip_set_boot_samples)");
+    if (e->nboot > e->result_cap) return fail(IQHIP_ERR_INVALID, "result buffer too small for the sample count");
+    HIPCHK(hipSetDevice(e->device));
+    int rc = scaled_pattern_lh(e, a, b);
+    if (rc) return rc;
+    HIPCHK(launch_rell(e, e->d_result));
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_rell(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b, double *rell) {
+    if (!rell) return fail(IQHIP_ERR_INVALID, "null argument");
+    int rc = iqhip_rell_async(e, a, b);
+    if (rc) return rc;
+    rc = read_result(e, e->nboot);
+    if (rc) return rc;
+    memcpy(rell, e->h_result, sizeof(double) * (size_t)e->nboot);
     return IQHIP_OK;
 }
 

@@ -115,6 +115,10 @@ struct iqhip_engine {
     double *d_slab = nullptr;   // wave partials [nvals][nwaves]
     int64_t slab_cap = 0;
     double *d_theta = nullptr, *d_pattern_lh = nullptr;
+    // UFBoot / RELL (kernels_rell.hip): scaled per-pattern lnL and the bootstrap sample matrix
+    double *d_ptn_scaled = nullptr;
+    float *d_boot = nullptr;  // [nboot][nptn_pad], zero padded
+    int nboot = 0;
     double *d_result_own = nullptr, *d_result = nullptr;
     double *d_newton_partials = nullptr;   // [2][num_cus][2]
     unsigned int *d_newton_barrier = nullptr;
@@ -156,6 +160,10 @@ hipError_t launch_reduce(iqhip_engine *e, int first_row, int nrows, int nwaves);
 // kernels_newton.hip
 hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps,
                          double *out);
+
+// kernels_rell.hip
+hipError_t launch_pattern_lh_scaled(iqhip_engine *e, const int16_t *sc_a, const int16_t *sc_b, double *out);
+hipError_t launch_rell(iqhip_engine *e, double *out);
 
 // kernels_mfma.hip (nstates 20 / 64)
 hipError_t launch_traverse_mfma(iqhip_engine *e, int nops, int nwaves);

@@ -214,6 +214,18 @@ int iqhost_fetch_partial(void *h, int from, int to, double *out) {
     });
 }
 int iqhost_fetch_pattern_lh(void *h, double *out) { IQHOST_TRY(((PhyloTree *)h)->fetchPatternLh(out)); }
+int iqhost_compute_pattern_likelihood(void *h, double *out) { IQHOST_TRY(((PhyloTree *)h)->computePatternLikelihood(out)); }
+int iqhost_set_boot_samples(void *h, const float *samples, int nsamples) {
+    IQHOST_TRY(((PhyloTree *)h)->setBootSamples(samples, nsamples));
+}
+int iqhost_compute_rell(void *h, double *out, int cap) {
+    IQHOST_TRY({
+        std::vector<double> r;
+        ((PhyloTree *)h)->computeRELL(r);
+        if ((int)r.size() > cap) throw std::runtime_error("output too small");
+        memcpy(out, r.data(), r.size() * sizeof(double));
+    });
+}
 
 // last submitted plan: 7 ints per op {dst_from, dst_to, left_node, right_node, left_leaf, right_leaf, 0}
 // plus 2 doubles per op {left_len, right_len}; dst_from->dst_to is the neighbour that was filled

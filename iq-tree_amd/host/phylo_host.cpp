@@ -908,4 +908,30 @@ void PhyloTree::fetchPatternLh(double *out) {
     check(iqhip_fetch_pattern_lh(engine, out), "iqhip_fetch_pattern_lh");
 }
 
+void PhyloTree::computePatternLikelihood(double *ptn_lh) {
+    if (!engine) throw std::runtime_error("no engine");
+    if (!current_it) throw std::runtime_error("computePatternLikelihood before computeLikelihood");
+    check(iqhip_fetch_pattern_lh_scaled(engine, branchEnd(current_it), branchEnd(current_it_back), ptn_lh),
+          "iqhip_fetch_pattern_lh_scaled");
+}
+
+void PhyloTree::setBootSamples(const float *samples, int nsamples) {
+    if (!engine) throw std::runtime_error("no engine");
+    pushInputs();
+    check(iqhip_set_boot_samples(engine, samples, nsamples), "iqhip_set_boot_samples");
+    num_boot_samples = nsamples;
+}
+
+void PhyloTree::computeRELL(std::vector<double> &rell) {
+    if (!engine) throw std::runtime_error("no engine");
+    if (!current_it) throw std::runtime_error("computeRELL before computeLikelihood");
+    rell.assign((size_t)num_boot_samples, 0.0);
+    if (allreduce_hook) {  // pattern shards: partial dot products are summed over the ranks
+        check(iqhip_rell_async(engine, branchEnd(current_it), branchEnd(current_it_back)), "iqhip_rell_async");
+        allreduce_hook(iqhip_result_device_ptr(engine), num_boot_samples, allreduce_ctx);
+        check(iqhip_result_read(engine, rell.data(), num_boot_samples), "iqhip_result_read");
+    } else
+        check(iqhip_rell(engine, branchEnd(current_it), branchEnd(current_it_back), rell.data()), "iqhip_rell");
+}
+
 }  // namespace iqhost

@@ -156,6 +156,15 @@ public:
     NNIMove getBestNNIForBran(PhyloNode *node1, PhyloNode *node2, bool nni5, NNIMove moves[2]);
     static const int NNI_MAX_NR_STEP = 10;  // phylotree.h
 
+    // ---- consumers of the per-pattern lnL (phylotree.cpp:1200-1230, iqtree.cpp:2676-2750) ----------
+    // computePatternLikelihood: lnL per pattern of the last computeLikelihood(), scaling events of
+    // both ends of current_it put back -- computed on the device, one D2H of nptn doubles
+    void computePatternLikelihood(double *ptn_lh);
+    // UFBoot: boot_samples uploaded once; computeRELL = saveCurrentTree's dot products, on the device
+    void setBootSamples(const float *samples /*[nsamples][nptn]*/, int nsamples);
+    void computeRELL(std::vector<double> &rell);
+    int num_boot_samples = 0;
+
     // ---- host views ----------------------------------------------------------------------
     void fetchScaleNum(PhyloNeighbor *nei, UBYTE *out);
     void fetchPartialLh(PhyloNeighbor *nei, double *out);

@@ -246,7 +246,7 @@ double oracle_partial_update(int n, int ncat, size_t nptn,
     /* like the reference (phylokernel.h:251,335,410: "#pragma omp parallel for reduction(+: sum_scale)"
      * over ptn); every pattern is independent */
 #ifdef _OPENMP
-#pragma omp parallel reduction(+ : sum_scale)
+#pragma omp parallel reduction(+ : sum_scale) if (nptn >= 2048) /* small test cases: no thread team */
     {
         double *tmp_t = (double *)malloc(sizeof(double) * n);
 #pragma omp for schedule(static)
@@ -510,4 +510,32 @@ void oracle_asc_theta_sums(int n, int ncat, size_t n_unobs, const double *eval, 
         out[2] += (d2[0] + d2[1]) + (d2[2] + d2[3]);
     }
     free(v0);
+}
+
+/* ---- UFBoot / RELL ---------------------------------------------------------------
+ * PhyloTree::computePatternLikelihood (phylotree.cpp:1200-1230): per-pattern lnL with the scaling
+ * events of both ends of the evaluated branch put back: ptn_lh = _pattern_lh + (sc_a + sc_b) * log(2^-256). */
+void oracle_pattern_lh_scaled(size_t nptn, const double *pattern_lh, const short *sc_a /* may be NULL */,
+                              const short *sc_b /* may be NULL */, double *out) {
+    for (size_t p = 0; p < nptn; p++) {
+        int s = (sc_a && sc_a[p] > 0 ? sc_a[p] : 0) + (sc_b && sc_b[p] > 0 ? sc_b[p] : 0);
+        out[p] = pattern_lh[p] + s * LOG_SCALING_THRESHOLD;
+    }
+}
+
+/* dotProductSIMD<float, Vec8f, 8> (phylokernel.h:55-61; dispatch phylotreeavx.cpp:26): eight float
+ * lanes, lane k accumulates terms k, k+8, ... with an unfused multiply-add, then
+ * horizontal_add(Vec8f) = ((l0+l1)+(l2+l3)) + ((l4+l5)+(l6+l7)) (vectorclass/vectorf256.h:897-903).
+ * The arrays are zero padded to a multiple of 8 by the caller (iqtree.cpp:2697-2699). */
+float oracle_dot_float8(const float *x, const float *y, size_t n) {
+    volatile float l[8];
+    for (int k = 0; k < 8; k++) l[k] = (k < (int)n) ? x[k] * y[k] : 0.0f;
+    for (size_t i = 8; i < n; i += 8)
+        for (int k = 0; k < 8 && i + k < n; k++) {
+            volatile float prod = x[i + k] * y[i + k];
+            l[k] = prod + l[k];
+        }
+    volatile float a = l[0] + l[1], b = l[2] + l[3], c = l[4] + l[5], d = l[6] + l[7];
+    volatile float ab = a + b, cd = c + d;
+    return ab + cd;
 }

@@ -57,6 +57,11 @@ def lib():
     L.oracle_asc_prob_const_branch.argtypes = [C.c_int, C.c_int, C.c_size_t, dp, dp, dp, C.c_double, dp, u8, dp, sp,
                                                dp, sp, dp]
     L.oracle_asc_prob_const_branch.restype = C.c_double
+    fp = C.POINTER(C.c_float)
+    L.oracle_pattern_lh_scaled.argtypes = [C.c_size_t, dp, sp, sp, dp]
+    L.oracle_pattern_lh_scaled.restype = None
+    L.oracle_dot_float8.argtypes = [fp, fp, C.c_size_t]
+    L.oracle_dot_float8.restype = C.c_float
     L.oracle_asc_theta_sums.argtypes = [C.c_int, C.c_int, C.c_size_t, dp, dp, dp, C.c_double, dp, sp, dp, dp]
     L.oracle_asc_theta_sums.restype = None
     _LIB = L
@@ -359,3 +364,22 @@ class OracleTree:
             if reps >= min_reps and dt >= budget_s:
                 break
         return reps * (self.ntaxa - 2) * self.nptn / dt / 1e6, reps, dt
+
+
+def dot_float8(x, y):
+    """The reference's UFBoot dot product (float, 8 AVX lanes); x, y float32."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    assert x.shape == y.shape and x.ndim == 1
+    fp = C.POINTER(C.c_float)
+    return float(lib().oracle_dot_float8(x.ctypes.data_as(fp), y.ctypes.data_as(fp), x.size))
+
+
+def pattern_lh_scaled(pattern_lh, sc_a, sc_b):
+    """PhyloTree::computePatternLikelihood: scaling events of both branch ends put back."""
+    p = np.ascontiguousarray(pattern_lh, dtype=np.float64)
+    out = np.zeros_like(p)
+    a = None if sc_a is None else np.ascontiguousarray(sc_a, dtype=np.int16)
+    b = None if sc_b is None else np.ascontiguousarray(sc_b, dtype=np.int16)
+    lib().oracle_pattern_lh_scaled(p.size, _dp(p), _sp(a), _sp(b), _dp(out))
+    return out

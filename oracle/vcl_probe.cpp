@@ -51,6 +51,23 @@ int main() {
         for (int k = 0; k < 4; k++)
             printf("[%.17g, %.17g]%s\n", x[k], l[k], (t == 63 && k == 3) ? "" : ",");
     }
+    printf("],\n\"dots8f\": [\n");
+    // 4) the UFBoot / RELL dot product: dotProductSIMD<float, Vec8f, 8> (phylokernel.h:55-61) on
+    //    pattern-lnL-like x (negative) and bootstrap-count-like y (small integers), zero padded to x8
+    int sizes8[5] = {8, 24, 64, 360, 1000};
+    for (int t = 0; t < 10; t++) {
+        int n = sizes8[t % 5];
+        static float x[1008] __attribute__((aligned(32))), y[1008] __attribute__((aligned(32)));
+        for (int i = 0; i < n; i++) { x[i] = (float)(-(rnd() + 1.0) * 25.0 - 0.5); y[i] = (float)(int)((rnd() + 1.0) * 2.5); }
+        Vec8f res = Vec8f().load_a(x) * Vec8f().load_a(y);
+        for (int i = 8; i < n; i += 8) res = mul_add(Vec8f().load_a(&x[i]), Vec8f().load_a(&y[i]), res);
+        float r = horizontal_add(res);
+        printf("{\"n\": %d, \"x\": [", n);
+        for (int i = 0; i < n; i++) printf("%s%.9g", i ? "," : "", x[i]);
+        printf("], \"y\": [");
+        for (int i = 0; i < n; i++) printf("%s%.9g", i ? "," : "", y[i]);
+        printf("], \"r\": %.9g}%s\n", r, t == 9 ? "" : ",");
+    }
     printf("]\n}\n");
     return 0;
 }

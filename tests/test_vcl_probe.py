@@ -37,3 +37,16 @@ def test_exp_log_within_one_ulp_of_vcl(oracle):
     worst_l = max(_ulps(L.oracle_log(x), y) for x, y in data["log"])
     # VCL's polynomials are not correctly rounded; libm is.  <= 1 ulp apart on these ranges.
     assert worst_e <= 1 and worst_l <= 1, (worst_e, worst_l)
+
+
+def test_float8_dot_product_is_bit_exact(oracle):
+    """UFBoot's dotProductSIMD<float, Vec8f, 8>: the oracle's scalar restatement vs the reference's own
+    Vec8f mul_add / horizontal_add (probe built from /root/reference/vectorclass)."""
+    data = json.load(open(GOLD))
+    assert len(data["dots8f"]) == 10
+    for d in data["dots8f"]:
+        x = np.array(d["x"], dtype=np.float32)
+        y = np.array(d["y"], dtype=np.float32)
+        assert x.size == d["n"]
+        got = oracle.dot_float8(x, y)
+        assert np.float32(got) == np.float32(d["r"]), (d["n"], got, d["r"])
