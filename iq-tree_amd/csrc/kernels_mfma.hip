@@ -26,6 +26,16 @@
 
 namespace iqhip {
 
+// constant-address-space view of the plan: the op descriptors are wave-uniform, so their fields become
+// s_load results (SGPRs), and pointers loaded through it are known to be global -- without it every
+// child load / result store is a FLAT instruction, which also counts in lgkmcnt and so is drained by
+// every wait on an LDS read.
+#define CONST_AS __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const CONST_AS T *as_const(const T *p) {
+    return (const CONST_AS T *)(p);
+}
+
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double wave_sum_m(double v) {
@@ -95,7 +105,7 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
         __syncthreads();
         for (int t = threadIdx.x; t < kn * 2 * B; t += WG) {
             const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B;
-            const DevOp &d = A.ops[k + o];
+            const CONST_AS DevOp &d = as_const(A.ops)[k + o];
             const double len = child ? d.right_len : d.left_len;
             sReg[(child ? d.lds_right : d.lds_left) + e] = exp(A.eval[e % N] * (A.rates[e / N] * len));
         }
@@ -103,7 +113,7 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
         if (!active) { k += kn; continue; }
 
         for (int kk = 0; kk < kn; kk++, k++) {
-            const DevOp &op = A.ops[k];
+            const CONST_AS DevOp &op = as_const(A.ops)[k];
             const bool leafL = op.left_kind == CHILD_LEAF, leafR = op.right_kind == CHILD_LEAF;
             const double *exL = sReg + op.lds_left, *exR = sReg + op.lds_right;
             // the scale counter of a pattern is carried by its g == 0 lane only, so that every
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
     const size_t tbase = (size_t)tl * 16 * B;     // doubles into a vector slab
     const double freq = A.freq[ptn];
     const double invar = A.invar[ptn];
-    const DevOp *ops = A.ops;
+    const CONST_AS DevOp *ops = as_const(A.ops);
 
     v4f64 prev[C][MTF];
     double prevT[C];  // tail rows 16*MTF+g
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
         __syncthreads();
         for (int t = threadIdx.x; t < kn * 2 * B; t += WG) {
             const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B;
-            const DevOp &d = ops[k + o];
+            const CONST_AS DevOp &d = ops[k + o];
             const double len = child ? d.right_len : d.left_len;
             sReg[(child ? d.lds_right : d.lds_left) + e] = exp(A.eval[e % N] * (A.rates[e / N] * len));
         }
@@ -293,8 +303,8 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
         if (!active) { k += kn; continue; }
 
         for (int kk = 0; kk < kn; kk++, k++) {
-            const DevOp &op = ops[k];
-            const DevOp &nxop = ops[k + 1];
+            const CONST_AS DevOp &op = ops[k];
+            const CONST_AS DevOp &nxop = ops[k + 1];
             const bool leafL = op.left_kind == CHILD_LEAF, leafR = op.right_kind == CHILD_LEAF;
             const double *exL = sReg + op.lds_left, *exR = sReg + op.lds_right;
             int sc = 0, sL = 0, sR = 0;
@@ -327,7 +337,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
             for (int c = 0; c < C; c++) {
                 // streamed child of the next step: (k, c+1) or (k+1, 0); its k-step slices replace the
                 // PFn registers one by one, right after this step has consumed them
-                const DevOp &nd = (c + 1 < C) ? op : nxop;
+                const CONST_AS DevOp &nd = (c + 1 < C) ? op : nxop;
                 const bool nreal = nd.real_mask & 1;
                 const double *nsrc = nd.pf + (nreal ? tbase + (size_t)((c + 1 < C) ? c + 1 : 0) * N * 16 : 0);
                 // N = 20 (5 k-steps): cheaper to copy the operands out and issue the whole prefetch up
@@ -382,6 +392,9 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
                         yl4 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4, xl, yl4, 0, 0, 0);
                         yr4 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4, xr, yr4, 0, 0, 0);
                     }
+                    // 64 states: keep the k-steps in program order, or the scheduler hoists all 16 operand
+                    // fetches above the first MFMA and the kernel spills
+                    if constexpr (STREAM) __builtin_amdgcn_sched_barrier(0);
                 }
                 if (c + 1 == C && g == 0) pfn_sc = nd.pf_sc[nreal ? ptn : (int64_t)p];
                 v4f64 T[MTF];
