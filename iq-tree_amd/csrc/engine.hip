@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <unordered_set>
 
 #include "iqhip_internal.h"
 
@@ -79,6 +80,7 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     }
     e->own_stream = true;
     if (const char *ab = getenv("IQHIP_ABLATE")) e->ablate = atoi(ab);
+    if (const char *sp = getenv("IQHIP_SPLIT")) e->split_target = atoi(sp);
     if (const char *kb = getenv("IQHIP_LDS_KB")) {
         int v = atoi(kb);
         if (v >= 8 && v <= 150) e->lds_budget_bytes = v * 1024;
@@ -405,8 +407,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         return IQHIP_OK;
     }
     e->last_plan_version = 0;
-    int rc = ensure_plan_capacity(e, nops + kSentinels);
-    if (rc) return rc;
+    int rc = IQHIP_OK;
     if (e->staging_busy) {  // the previous submission may still be copying h_ops
         HIPCHK(hipEventSynchronize(e->staging_free));
         e->staging_busy = false;
@@ -414,6 +415,98 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
     int prev_dst = -1;
     const int B = e->block;
     e->plan_has_load = false;
+    e->plan_units_have_load = false;
+    // ---- staging.  A launch gives every 64/16-pattern tile one wave that walks the whole op list, so an
+    // alignment with few tiles leaves SIMDs idle or unevenly loaded (a tile is an indivisible unit of
+    // nops updates).  Independent subtrees of the plan are therefore cut out as "units" that run on
+    // their own workgroups in a first launch (tiles x units waves), and only the ops above them
+    // ("top") walk sequentially in a second launch.  order[p] = caller index of the op at position p.
+    std::vector<int> order(nops), seg_of(nops, 0);
+    std::vector<std::pair<int, int>> units;  // {begin, nops} in the new order
+    int top_begin = 0;
+    for (int k = 0; k < nops; k++) order[k] = k;
+    {
+        int target = e->split_target;
+        const int64_t simds = (int64_t)e->num_cus * 4;
+        if (target < 0) {
+            // auto: the matrix-core kernels (16-pattern tiles, long per-tile op lists) when there are fewer
+            // than 6 tile-waves per SIMD; unit size so that the first launch has ~4 waves per SIMD.
+            // Measured at the BASELINE shapes: protein 1.28 -> 1.10 ms, codon 0.64 -> 0.49 ms; the 4-state
+            // kernel is store-bound and loses (0.161 -> 0.172..0.184 ms), so it stays unsplit.
+            target = 0;
+            if (e->mfma && e->ntiles < 6 * simds && nops >= 12)
+                target = (int)std::min<int64_t>(nops / 2, std::max<int64_t>(3, ((int64_t)nops * e->ntiles + 4 * simds - 1) / (4 * simds)));
+        }
+        if (target > 0 && target < nops && nops >= 4) {
+            std::unordered_map<uint64_t, int> prod;
+            std::unordered_set<uint64_t> ext_in;
+            std::vector<int> lc(nops, -1), rc(nops, -1), sz(nops, 1);
+            std::vector<char> consumed(nops, 0), contiguous(nops, 1);
+            bool safe = true;
+            for (int k = 0; k < nops && safe; k++) {
+                const iqhip_node_op &o = ops[k];
+                auto child = [&](uint64_t key, int32_t leaf) -> int {
+                    if (leaf >= 0) return -1;
+                    auto it = prod.find(key);
+                    if (it == prod.end()) { ext_in.insert(key); return -1; }
+                    return it->second;
+                };
+                lc[k] = child(o.left_key, o.left_leaf);
+                rc[k] = child(o.right_key, o.right_leaf);
+                if (lc[k] >= 0) { if (consumed[lc[k]]) safe = false; consumed[lc[k]] = 1; sz[k] += sz[lc[k]]; }
+                if (rc[k] >= 0) { if (consumed[rc[k]]) safe = false; consumed[rc[k]] = 1; sz[k] += sz[rc[k]]; }
+                // post-order contiguity: the subtree of k is exactly [k - sz + 1, k]
+                const int a = std::max(lc[k], rc[k]), b2 = std::min(lc[k], rc[k]);
+                bool cont = true;
+                if (a >= 0) cont = (a == k - 1) && contiguous[a];
+                if (b2 >= 0) cont = cont && (b2 == a - sz[a]) && contiguous[b2];
+                contiguous[k] = cont;
+                // re-ordering is only safe when no vector of the plan is both an outside input and a
+                // destination (LM_PER_NODE buffer stealing) and nothing is written twice
+                if (prod.count(o.dst_key)) safe = false;
+                prod[o.dst_key] = k;
+            }
+            for (int k = 0; k < nops && safe; k++)
+                if (ext_in.count(ops[k].dst_key)) safe = false;
+            if (safe) {
+                std::vector<char> in_unit(nops, 0);
+                std::vector<int> stack;
+                for (int k = nops - 1; k >= 0; k--)
+                    if (!consumed[k]) stack.push_back(k);
+                std::vector<std::pair<int, int>> found;  // {root, size}
+                while (!stack.empty()) {
+                    const int k = stack.back();
+                    stack.pop_back();
+                    if (sz[k] <= target && sz[k] >= 2 && contiguous[k]) {
+                        found.push_back({k, sz[k]});
+                        for (int q = k - sz[k] + 1; q <= k; q++) in_unit[q] = 1;
+                    } else {
+                        if (lc[k] >= 0) stack.push_back(lc[k]);
+                        if (rc[k] >= 0) stack.push_back(rc[k]);
+                    }
+                }
+                if (found.size() >= 2) {
+                    std::stable_sort(found.begin(), found.end(),
+                                     [](const std::pair<int, int> &x, const std::pair<int, int> &y2) { return x.second > y2.second; });
+                    int pos = 0;
+                    for (size_t u = 0; u < found.size(); u++) {
+                        units.push_back({pos, found[u].second});
+                        for (int q = found[u].first - found[u].second + 1; q <= found[u].first; q++) {
+                            seg_of[pos] = (int)u + 1;
+                            order[pos++] = q;
+                        }
+                    }
+                    top_begin = pos;
+                    for (int k = 0; k < nops; k++)
+                        if (!in_unit[k]) { seg_of[pos] = 0; order[pos++] = k; }
+                }
+            }
+        }
+    }
+    const int table_ints = 2 * (1 + (int)units.size());
+    const int table_ops = (int)((table_ints * sizeof(int) + sizeof(DevOp) - 1) / sizeof(DevOp));
+    rc = ensure_plan_capacity(e, nops + kSentinels + table_ops);
+    if (rc) return rc;
     auto dummy_op = [&](DevOp &d) {
         memset(&d, 0, sizeof(d));
         d.dst = e->dummy.plh;
@@ -423,9 +516,11 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         d.sl = d.sr = e->d_states;
     };
     for (int k = 0; k < nops; k++) {
-        const iqhip_node_op &o = ops[k];
+        const iqhip_node_op &o = ops[order[k]];
         DevOp &d = e->h_ops[k];
         dummy_op(d);
+        d.out_row = order[k];
+        if (k > 0 && seg_of[k] != seg_of[k - 1]) prev_dst = -1;  // another workgroup: no register hand-over
         if (!(o.left_len >= 0.0) || !(o.right_len >= 0.0))
             return fail(IQHIP_ERR_INVALID, "negative or NaN branch length");
         const double *lp, *rp;
@@ -461,7 +556,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
             if (lkind == CHILD_PREV) swap_children();                              // PREV goes right
             else if (lkind == CHILD_LEAF && rkind == CHILD_LOAD) swap_children();  // memory child goes left
             if (lkind == CHILD_LOAD) lkind = CHILD_PF;
-            if (rkind == CHILD_LOAD) e->plan_has_load = true;                      // (PF, LOAD)
+            if (rkind == CHILD_LOAD) { if (seg_of[k]) e->plan_units_have_load = true; else e->plan_has_load = true; }  // (PF, LOAD)
             if (lkind == CHILD_PF) { d.pf = lp; d.pf_sc = lsc; d.real_mask |= 1; }
             if (rkind == CHILD_LOAD) { d.ld = rp; d.ld_sc = rsc; }
             if (lkind == CHILD_LEAF) d.sl = lst;
@@ -485,7 +580,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
                 auto it = producer.find(d.pf);
                 if (it != producer.end()) {
                     const int j = it->second;
-                    bool ok = !e->h_ops[j].push_hold;
+                    bool ok = !e->h_ops[j].push_hold && seg_of[j] == seg_of[k];
                     for (int q = j + 1; q < k && ok; q++) {
                         const DevOp &m = e->h_ops[q];
                         ok = m.left_kind != CHILD_PF && m.left_kind != CHILD_HOLD && m.right_kind != CHILD_LOAD &&
@@ -529,7 +624,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
             const int nleaf = (d.left_kind == CHILD_LEAF) + (d.right_kind == CHILD_LEAF);
             const int need = szl + szr + (e->mfma ? 0 : nleaf * e->wg_size / 8);
             if (need > budget) return fail(IQHIP_ERR_UNSUPPORTED, "nstates*ncat too large for the LDS plan regions");
-            if (used + need > budget && k > chunk_start) {
+            if ((used + need > budget || seg_of[k] != seg_of[k - (k > 0)]) && k > chunk_start) {
                 e->h_ops[chunk_start].chunk_nops = k - chunk_start;
                 chunk_start = k;
                 used = e->mfma ? 0 : e->wg_size / 8;  // slot 0
@@ -551,7 +646,16 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
     }
     // the descriptors of a repeated plan (model-parameter optimisation re-evaluates the same
     // tree) are already on the device: skip the upload, never the computation
-    const size_t nbytes = sizeof(DevOp) * (size_t)(nops + kSentinels);
+    {
+        int *tab = reinterpret_cast<int *>(e->h_ops + nops + kSentinels);
+        memset(tab, 0, sizeof(DevOp) * (size_t)table_ops);
+        tab[0] = top_begin;
+        tab[1] = nops - top_begin;
+        for (size_t u = 0; u < units.size(); u++) { tab[2 + 2 * u] = units[u].first; tab[3 + 2 * u] = units[u].second; }
+        e->plan_nunits = (int)units.size();
+        e->plan_table_off = nops + kSentinels;
+    }
+    const size_t nbytes = sizeof(DevOp) * (size_t)(nops + kSentinels + table_ops);
     e->last_ops_in.assign((const char *)ops, (const char *)ops + in_bytes);
     e->last_plan_version = e->keymap_version;  // (slabs created while building are included)
     e->last_plan_dst = prev_dst;
@@ -613,8 +717,13 @@ static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, 
     if (rc) return rc;
     const int nwaves = (int)e->ntiles;
     timing_begin(e);
-    if (e->mfma) HIPCHK(launch_traverse_mfma(e, nops, nwaves));
-    else HIPCHK(launch_traverse4(e, nops, has_root ? &br : nullptr, nwaves));
+    const int *table = reinterpret_cast<const int *>(e->d_ops + e->plan_table_off);
+    if (e->plan_nunits > 0) {  // stage 1: the independent subtrees, one set of workgroups each
+        if (e->mfma) HIPCHK(launch_traverse_mfma(e, table + 2, e->plan_nunits, nwaves));
+        else HIPCHK(launch_traverse4(e, table + 2, e->plan_nunits, e->plan_units_have_load, nullptr, nwaves));
+    }
+    if (e->mfma) HIPCHK(launch_traverse_mfma(e, table, nops > 0 ? 1 : 0, nwaves));
+    else HIPCHK(launch_traverse4(e, table, 1, e->plan_has_load, has_root ? &br : nullptr, nwaves));
     timing_end(e);
     if (e->mfma && has_root) HIPCHK(launch_stream_mfma(e, 0, &br, br.len, nwaves));
     if (has_root) HIPCHK(launch_reduce(e, 0, 2 + nops, nwaves));

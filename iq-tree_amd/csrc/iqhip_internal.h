@@ -50,7 +50,7 @@ struct __attribute__((aligned(16))) DevOp {
     int32_t sl_slot;    // LDS slot of the staged leaf states of the left / right child within
     int32_t sr_slot;    //   the chunk (slot 0 is shared by all non-leaf children)
     int32_t push_hold;  // 1: copy this op's result into the HOLD registers (consumed by a CHILD_HOLD)
-    int32_t _pad;
+    int32_t out_row;    // row of the caller's op list this op answers (sum_scale[out_row]); plans may be reordered
 };
 
 // Root branch descriptor for the lnL / theta kernels.
@@ -87,6 +87,13 @@ struct iqhip_engine {
     int plan_lds_doubles = 0;
     int plan_state_slots = 1;    // leaf-state LDS slots of the largest chunk (4-state path)
     bool plan_has_load = false;  // some op has two memory children (slow kernel instantiation)
+    // Staged plans (engine.hip, build_plan): independent subtrees ("units") run as their own workgroups in a
+    // first launch, the ops above them ("top") in a second one.  Segment table on the device, after the
+    // sentinel descriptors: {top_begin, top_nops, unit1_begin, unit1_nops, ...}
+    int plan_nunits = 0;
+    int plan_table_off = 0;      // DevOp index where the table starts
+    bool plan_units_have_load = false;
+    int split_target = -1;       // IQHIP_SPLIT: -1 auto, 0 never, n > 0: unit size
     iqhip::Slab dummy;           // valid target of unconditional prefetches  // LDS region size (doubles) of the largest chunk of the current plan
     int block = 0;         // n*ncat
     int state_unknown = -1;
@@ -151,7 +158,8 @@ struct iqhip_engine {
 namespace iqhip {
 
 // kernels_valu4.hip
-hipError_t launch_traverse4(iqhip_engine *e, int nops, const DevBranch *root, int nwaves);
+// seg_table: device ints {begin, nops} x nsegs; every segment runs on its own set of workgroups
+hipError_t launch_traverse4(iqhip_engine *e, const int *seg_table, int nsegs, bool has_load, const DevBranch *root, int nwaves);
 hipError_t launch_theta4(iqhip_engine *e, const DevBranch &br);
 hipError_t launch_derv4(iqhip_engine *e, double len, int nwaves);
 hipError_t launch_lnl_theta4(iqhip_engine *e, double len, int nwaves);
@@ -166,7 +174,7 @@ hipError_t launch_pattern_lh_scaled(iqhip_engine *e, const int16_t *sc_a, const 
 hipError_t launch_rell(iqhip_engine *e, double *out);
 
 // kernels_mfma.hip (nstates 20 / 64)
-hipError_t launch_traverse_mfma(iqhip_engine *e, int nops, int nwaves);
+hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs, int nwaves);
 int mfma2_fixed_lds_doubles(int n);
 // mode 0: branch lnL, 1: theta, 2: df/ddf from theta, 3: lnL from theta
 hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, double len, int nwaves);

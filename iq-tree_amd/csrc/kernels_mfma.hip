@@ -56,7 +56,9 @@ struct TravMArgs {
     double *slab;           // [nvals][nwaves]
     int64_t ntiles;         // tiles of 16 patterns
     int64_t nptn;
-    int nops;
+    const int *segs;        // {begin, nops} per segment; workgroup b works on segment b / ngroups
+    int ngroups;            // workgroups per segment
+    int nsegs_launch; // host side only: segments of this launch
     int nwaves;
     int ncat;
     int state_unknown;
@@ -90,7 +92,9 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t tile = (int64_t)blockIdx.x * WPB + wave;
+    const int seg = (int)blockIdx.x / A.ngroups;  // scalar
+    const int k_begin = as_const(A.segs)[2 * seg], k_end = k_begin + as_const(A.segs)[2 * seg + 1];
+    const int64_t tile = (int64_t)((int)blockIdx.x - seg * A.ngroups) * WPB + wave;
     const bool active = tile < A.ntiles;
     const int64_t tl = active ? tile : 0;
     const int p = lane & 15, g = lane >> 4;
@@ -99,8 +103,8 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
     const double freq = A.freq[ptn];
     const double invar = A.invar[ptn];
 
-    int k = 0;
-    while (k < A.nops) {
+    int k = k_begin;
+    while (k < k_end) {
         const int kn = A.ops[k].chunk_nops;
         __syncthreads();
         for (int t = threadIdx.x; t < kn * 2 * B; t += WG) {
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
             }
             if (g == 0) op.dst_sc[ptn] = (int16_t)sc;
             const double ws = wave_sum_m(my_scale);
-            if (lane == 0) A.slab[(size_t)(2 + k) * A.nwaves + (int)tl] = ws;
+            if (lane == 0) A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
         }
     }
 }
@@ -261,7 +265,9 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t tile = (int64_t)blockIdx.x * WPB + wave;
+    const int seg = (int)blockIdx.x / A.ngroups;  // scalar
+    const int k_begin = as_const(A.segs)[2 * seg], k_end = k_begin + as_const(A.segs)[2 * seg + 1];
+    const int64_t tile = (int64_t)((int)blockIdx.x - seg * A.ngroups) * WPB + wave;
     const bool active = tile < A.ntiles;
     const int64_t tl = active ? tile : 0;
     const int p = lane & 15, g = lane >> 4;
@@ -282,15 +288,16 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
     int prev_sc = 0;
     double PFn[KS];
     int pfn_sc = 0;
-    {   // prime: streamed child of (op 0, category 0); ops[nops..] are sentinels
-        const double *src = ops[0].pf + ((ops[0].real_mask & 1) ? tbase : 0);
+    {   // prime: streamed child of (first op, category 0); the op after the last one is a sentinel
+        const CONST_AS DevOp &f = ops[k_begin];
+        const double *src = f.pf + ((f.real_mask & 1) ? tbase : 0);
 #pragma unroll
         for (int s = 0; s < KS; s++) PFn[s] = src[s * 64 + lane];
-        if (g == 0) pfn_sc = ops[0].pf_sc[(ops[0].real_mask & 1) ? ptn : (int64_t)p];
+        if (g == 0) pfn_sc = f.pf_sc[(f.real_mask & 1) ? ptn : (int64_t)p];
     }
 
-    int k = 0;
-    while (k < A.nops) {
+    int k = k_begin;
+    while (k < k_end) {
         const int kn = ops[k].chunk_nops;
         __syncthreads();
         for (int t = threadIdx.x; t < kn * 2 * B; t += WG) {
@@ -433,13 +440,17 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int row = 16 * m + 4 * r + g;
+#ifndef IQHIP_MFMA_ABLATE_NOSTORE  // timing-only build switch; never defined in the shipped library
                         dst[(size_t)(c * N + row) * 16 + p] = O[m][r];
+#endif
                         lmax = fmax(lmax, fabs(O[m][r]));
                     }
                 }
                 if (TAIL4) {
                     prevT[c] = o4;
+#ifndef IQHIP_MFMA_ABLATE_NOSTORE
                     dst[(size_t)(c * N + 16 * MTF + g) * 16 + p] = o4;
+#endif
                     lmax = fmax(lmax, fabs(o4));
                 }
             }
@@ -470,7 +481,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
             prev_sc = sc;
             if (g == 0) op.dst_sc[ptn] = (int16_t)sc;
             const double ws = wave_sum_m(my_scale);
-            if (lane == 0) A.slab[(size_t)(2 + k) * A.nwaves + (int)tl] = ws;
+            if (lane == 0) A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
         }
     }
 }
@@ -486,7 +497,8 @@ static hipError_t launch_trav_m(iqhip_engine *e, TravMArgs &A) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const int grid = (int)((A.ntiles + 3) / 4);
+    A.ngroups = (int)((A.ntiles + 3) / 4);
+    const int grid = A.ngroups * A.nsegs_launch;
     hipLaunchKernelGGL((k_traverse_mfma<N, WG>), dim3(grid), dim3(WG), lds, e->stream, A);
     return hipGetLastError();
 }
@@ -508,12 +520,13 @@ static hipError_t launch_trav_m2(iqhip_engine *e, TravMArgs &A) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const int grid = (int)((A.ntiles + 3) / 4);
+    A.ngroups = (int)((A.ntiles + 3) / 4);
+    const int grid = A.ngroups * A.nsegs_launch;
     hipLaunchKernelGGL((k_traverse_mfma2<N, C, WG>), dim3(grid), dim3(WG), lds, e->stream, A);
     return hipGetLastError();
 }
 
-hipError_t launch_traverse_mfma(iqhip_engine *e, int nops, int nwaves) {
+hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs, int nwaves) {
     TravMArgs A;
     A.ops = e->d_ops;
     A.evec = e->d_evec;
@@ -526,11 +539,12 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, int nops, int nwaves) {
     A.slab = e->d_slab;
     A.ntiles = e->ntiles;
     A.nptn = e->nptn;
-    A.nops = nops;
+    A.segs = seg_table;
+    A.nsegs_launch = nsegs;
     A.nwaves = nwaves;
     A.ncat = e->ncat;
     A.state_unknown = e->state_unknown;
-    if (nops <= 0) return hipSuccess;
+    if (nsegs <= 0) return hipSuccess;
     if (e->mfma_pipelined) {  // plan was built in canonical (PF, PREV) form
         if (e->n == 20 && e->ncat == 4) return launch_trav_m2<20, 4>(e, A);
         if (e->n == 20 && e->ncat == 1) return launch_trav_m2<20, 1>(e, A);

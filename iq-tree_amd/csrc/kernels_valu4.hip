@@ -91,11 +91,14 @@ struct Trav4Args {
     int64_t ntiles;
     int64_t nptn;
     int64_t nobs;      // observed patterns; [nobs, nptn) are the +ASC unobserved constant patterns
-    int nops;
+    const int *segs;   // {begin, nops} per segment; workgroup b works on segment b / ngroups
+    int ngroups;       // workgroups per segment
     int nwaves;
     int state_unknown;
     int has_root;
     int lds_reg_doubles;  // size of the per-branch region area (largest chunk)
+    int nsegs_launch;     // host side only: segments of this launch, instantiation choice
+    int has_load;
     DevBranch root;
 };
 
@@ -259,7 +262,9 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // make it provably uniform
-    const int64_t tile = (int64_t)blockIdx.x * WPB + wave;
+    const int seg = (int)blockIdx.x / A.ngroups;  // scalar
+    const int k_begin = as_const(A.segs)[2 * seg], k_end = k_begin + as_const(A.segs)[2 * seg + 1];
+    const int64_t tile = (int64_t)((int)blockIdx.x - seg * A.ngroups) * WPB + wave;
     const bool active = tile < A.ntiles;
     const int64_t tl = active ? tile : 0;
     const int gw = (int)tl;               // global wave id == tile id
@@ -284,15 +289,15 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
     // everything op k needs from memory is requested while op k-1 computes.  Prime for op 0.
     // (ops[nops] is a sentinel whose pointers are valid dummies, so the requests are unconditional)
     if (active) {
-        const CONST_AS DevOp *nx = ops;
+        const CONST_AS DevOp *nx = ops + k_begin;
         const int nreal = nx->real_mask;
         load_vec4_off<C>(nx->pf, (nreal & 1) ? voff : (uint32_t)(lane * 16), PF);
         pf_sc = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(nx->pf_sc) +
                                                    ((nreal & 1) ? soff : (uint32_t)(lane * 2)));
     }
 
-    int k = 0;
-    while (k < A.nops) {
+    int k = k_begin;
+    while (k < k_end) {
         // ---- fill the LDS regions of the chunk that starts at op k (host-chosen boundaries)
         const int kn = ops[k].chunk_nops;
         __syncthreads();  // the previous chunk's regions are no longer read
@@ -394,10 +399,10 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
             // deterministic reduction: wave partial -> slab[2+k][gw]
             double ws = 0.0;
             if (any) ws = wave_sum(my_scale);
-            if (lane == 0) A.slab[(size_t)(2 + k) * A.nwaves + gw] = ws;
+            if (lane == 0) A.slab[(size_t)(2 + op->out_row) * A.nwaves + gw] = ws;
         }
     }
-    if (A.nops == 0) __syncthreads();  // s_tip / s_val visibility for a root-only launch
+    if (k_end == k_begin) __syncthreads();  // s_tip / s_val visibility for a root-only launch
     if (!active) return;
 
     if (A.has_root) {
@@ -461,14 +466,14 @@ static hipError_t launch_trav_l(iqhip_engine *e, Trav4Args &A) {
         attr_set = true;
     }
     constexpr int WPB = WG / 64;
-    const int grid = (int)((e->ntiles + WPB - 1) / WPB);
-    hipLaunchKernelGGL((k_traverse4<C, WG, HAS_LOAD>), dim3(grid), dim3(WG), lds, e->stream, A);
+    A.ngroups = (int)((e->ntiles + WPB - 1) / WPB);
+    hipLaunchKernelGGL((k_traverse4<C, WG, HAS_LOAD>), dim3((unsigned)(A.ngroups * A.nsegs_launch)), dim3(WG), lds, e->stream, A);
     return hipGetLastError();
 }
 
 template <int C, int WG>
 static hipError_t launch_trav_c(iqhip_engine *e, Trav4Args &A) {
-    return e->plan_has_load ? launch_trav_l<C, WG, true>(e, A) : launch_trav_l<C, WG, false>(e, A);
+    return A.has_load ? launch_trav_l<C, WG, true>(e, A) : launch_trav_l<C, WG, false>(e, A);
 }
 
 template <int C>
@@ -480,7 +485,7 @@ static hipError_t launch_trav_wg(iqhip_engine *e, Trav4Args &A) {
     }
 }
 
-hipError_t launch_traverse4(iqhip_engine *e, int nops, const DevBranch *root, int nwaves) {
+hipError_t launch_traverse4(iqhip_engine *e, const int *seg_table, int nsegs, bool has_load, const DevBranch *root, int nwaves) {
     Trav4Args A;
     A.ops = e->d_ops;
     A.evec = e->d_evec;
@@ -496,7 +501,9 @@ hipError_t launch_traverse4(iqhip_engine *e, int nops, const DevBranch *root, in
     A.ntiles = e->ntiles;
     A.nptn = e->nptn;
     A.nobs = e->nptn - e->n_unobs;
-    A.nops = nops;
+    A.segs = seg_table;
+    A.nsegs_launch = nsegs;
+    A.has_load = has_load ? 1 : 0;
     A.nwaves = nwaves;
     A.state_unknown = e->state_unknown;
     A.has_root = root ? 1 : 0;
