@@ -647,3 +647,56 @@ def test_nni_evaluation_on_scratch_buffers(pkg, synth, oracle, nni5):
         t.clear_all_partial_lh()
         assert abs(t.compute_likelihood() - base) <= 1e-12 * abs(base)
     assert abs(base - ref0) <= LNL_RTOL * abs(ref0)
+
+
+# ------------------------------------------------------------------------------------------
+# staged plans (engine.hip build_plan): units of independent subtrees + top stage
+# ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n,ncat,seq_type,ntaxa,cat", [(4, 4, 0, 40, False), (4, 4, 0, 60, True), (20, 4, 1, 30, False),
+                                                        (64, 1, 2, 20, False), (20, 2, 1, 24, False)])
+@pytest.mark.parametrize("mem_mode", [0, 1])
+def test_staged_plans_give_identical_results(pkg, synth, oracle, n, ncat, seq_type, ntaxa, cat, mem_mode, monkeypatch):
+    """IQHIP_SPLIT=0 (one launch) against forced unit sizes: every vector, scale counter and
+    lh_scale_factor must come out the same, the lnL to rounding (the per-op partial sums are the same
+    numbers; only the launch structure differs)."""
+    kw = dict(lo=0.3, hi=0.8, caterpillar=True) if cat else dict(missing=0.03)
+    results = []
+    for split in ("0", "3", "7", "1000"):
+        monkeypatch.setenv("IQHIP_SPLIT", split)
+        t, ot, *_ = make_case(synth, oracle, pkg, ntaxa, 333, n, ncat, 4000 + n + ntaxa, seq_type=seq_type,
+                              mem_mode=mem_mode, **kw)
+        lnl = t.compute_likelihood()
+        a, b = t.current_branch()
+        info = t.neighbor_info(a, b)
+        vec = t.fetch_partial(a, b)
+        sc = t.fetch_scale_num(a, b)
+        if split == "0":
+            ref, _ = ot.likelihood()
+            assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+            assert check_all_vectors(t, ot) == ntaxa - 2
+        # partial re-evaluation after a branch change deep in the tree (short plans, lazy flags)
+        inner = [(x, y) for x in range(t.num_nodes) for y, _ in t.neighbors(x) if x < y]
+        x, y = inner[len(inner) // 2]
+        t.set_branch_length(x, y, 0.21)
+        lnl2 = t.compute_likelihood()
+        results.append((lnl, info["lh_scale_factor"], vec, sc, lnl2))
+    base = results[0]
+    for r in results[1:]:
+        assert abs(r[0] - base[0]) <= 1e-13 * abs(base[0]) and r[1] == base[1]
+        assert np.array_equal(r[2], base[2]) and np.array_equal(r[3], base[3])
+        assert abs(r[4] - base[4]) <= 1e-13 * abs(base[4])
+
+
+def test_staged_plan_is_refused_for_reused_buffers(pkg, synth, oracle, monkeypatch):
+    """LM_PER_NODE re-orientation inside one submission (a vector that is both an outside input and a
+    destination) must not be re-ordered: evaluate on a far branch, then on the opposite side."""
+    monkeypatch.setenv("IQHIP_SPLIT", "3")
+    t, ot, *_ = make_case(synth, oracle, pkg, 30, 200, 4, 4, 515)
+    ref, _ = ot.likelihood()
+    assert abs(t.compute_likelihood() - ref) <= LNL_RTOL * abs(ref)
+    leaves = [v for v in range(t.num_nodes) if ot.is_leaf(v)]
+    for leaf in leaves[::5]:
+        nb = t.neighbors(leaf)[0][0]
+        v = t.compute_likelihood_branch(leaf, nb)      # re-roots: steals buffers of the old orientation
+        assert abs(v - ref) <= LNL_RTOL * abs(ref)
