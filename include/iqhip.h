@@ -199,8 +199,9 @@ int iqhip_rell_async(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b);
 int iqhip_upload_partial(iqhip_engine *e, uint64_t key, const double *partial_lh,
                          const int16_t *scale_num);
 
-/* Measurement hook for bench.py: average device time (ms) of the dominant kernel over the
- * launches since the last reset, measured with HIP events on the engine's stream. */
+/* Measurement hook for bench.py: average device time (ms) per launch of the traversal kernel over the
+ * launches since the last reset (a staged plan is two launches per traversal), measured with HIP
+ * events on the engine's stream. */
 int iqhip_timing_enable(iqhip_engine *e, int on);
 int iqhip_timing_read(iqhip_engine *e, double *avg_ms, int64_t *launches, int reset);
 

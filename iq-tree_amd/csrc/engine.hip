@@ -725,6 +725,7 @@ static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, 
     if (e->mfma) HIPCHK(launch_traverse_mfma(e, table, nops > 0 ? 1 : 0, nwaves));
     else HIPCHK(launch_traverse4(e, table, 1, e->plan_has_load, has_root ? &br : nullptr, nwaves));
     timing_end(e);
+    if (e->timing) e->tev_launches += (e->plan_nunits > 0) ? 2 : 1;
     if (e->mfma && has_root) HIPCHK(launch_stream_mfma(e, 0, &br, br.len, nwaves));
     if (has_root) HIPCHK(launch_reduce(e, 0, 2 + nops, nwaves));
     else HIPCHK(launch_reduce(e, 2, nops, nwaves));
@@ -1142,8 +1143,10 @@ extern "C" int iqhip_timing_read(iqhip_engine *e, double *avg_ms, int64_t *launc
         HIPCHK(hipEventElapsedTime(&ms, e->tev[i].first, e->tev[i].second));
         total += ms;
     }
-    if (avg_ms) *avg_ms = e->tev_used ? total / (double)e->tev_used : 0.0;
-    if (launches) *launches = (int64_t)e->tev_used;
-    if (reset) e->tev_used = 0;
+    // a staged plan is two launches of the traversal kernel inside one bracket: report per launch, as a
+    // profiler's per-kernel average does
+    if (avg_ms) *avg_ms = e->tev_launches ? total / (double)e->tev_launches : 0.0;
+    if (launches) *launches = e->tev_launches;
+    if (reset) { e->tev_used = 0; e->tev_launches = 0; }
     return IQHIP_OK;
 }

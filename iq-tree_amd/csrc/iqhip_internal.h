@@ -152,6 +152,7 @@ struct iqhip_engine {
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;
     size_t tev_used = 0;
+    int64_t tev_launches = 0;  // traversal-kernel launches inside the recorded brackets
     int last_nops = 0;
 };
 
