@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["dna", "protein", "codon"], default="dna",
+    ap.add_argument("--workload", choices=["dna", "protein", "codon", "mixture"], default="dna",
                     help="dna = BASELINE configs[1] (the headline); protein/codon = configs[2]/[4] shapes")
     ap.add_argument("--ntaxa", type=int, default=0)
     ap.add_argument("--patterns", type=int, default=0, help="patterns per GPU")
@@ -91,10 +91,16 @@ def main():
     lib = pkg.libiqhip()
 
     shapes = {"dna": (50, 100000, 4, 4, pkg.SEQ_DNA), "protein": (100, 50000, 20, 4, pkg.SEQ_PROTEIN),
-              "codon": (50, 20000, 64, 1, pkg.SEQ_CODON)}
+              "codon": (50, 20000, 64, 1, pkg.SEQ_CODON),
+              # protein profile mixture x Gamma (C10+G4 shape: 10 classes x 4 rates = 40 components)
+              "mixture": (50, 10000, 20, 40, pkg.SEQ_PROTEIN)}
     T0, P0, nst, ncat, seq_type = shapes[args.workload]
     T, P = args.ntaxa or T0, args.patterns or P0
-    if nst == 4:
+    sim_model = None
+    if args.workload == "mixture":
+        model = synth.mixture_model(20, 10, 7, alpha=0.9, ncat=4)
+        sim_model = model.classes[0]
+    elif nst == 4:
         model = synth.gtr_model(rates6=(1.5, 2.4, 1.8, 1.9, 2.8, 1.0), freqs=(0.25, 0.26, 0.25, 0.24),
                                 alpha=0.9, ncat=4)
     else:
@@ -106,7 +112,7 @@ def main():
     nwk = synth.random_tree_newick(T, 1)
     nsites = int(P * 1.02) + 64
     while True:
-        st = synth.simulate_alignment(nwk, model, nsites, 1000 + rank)
+        st = synth.simulate_alignment(nwk, sim_model or model, nsites, 1000 + rank)
         pat, freq = synth.compress_patterns(st)
         if pat.shape[1] >= P:
             break
@@ -223,7 +229,7 @@ def main():
 
     if rank == 0 and not args.no_cpu_baseline:
         od = entry.load_oracle()
-        sample = min(P, 100000 if nst == 4 else 4000)
+        sample = min(P, 100000 if nst == 4 else (4000 if model.ncat <= 4 else 1000))
         ot = od.OracleTree(nwk, nst, seq_type, pat[:, :sample], freq[:sample], None, model)
         try:
             ncores = min(len(os.sched_getaffinity(0)), 16)

@@ -119,6 +119,18 @@ int iqhip_set_model(iqhip_engine *e, const double *eval, const double *evec,
                     const double *inv_evec, const double *rates, const double *props,
                     int state_unknown, const double *tip_partial_lh);
 
+/* Mixture models (computeMixturePartialLikelihoodEigenSIMD & co, phylokernelmixture.h:20-460; fused
+ * mixture-rate models, phylokernelmixrate.h:22-450).  The engine's ncat categories are the (class, rate)
+ * components in the reference's block order [class][rate] (block = nstates*ncat*nmixture there,
+ * phylokernelmixture.h:55-56): component q uses eigen-system cat_class[q], rate rates[q] and weight
+ * props[q] (= class weight x category proportion).  eval / evec / inv_evec are the nclass systems
+ * concatenated (model->getEigenvalues() etc. of ModelMixture); tip_partial_lh is [state][class][n]
+ * (phylotreesse.cpp:395-458, phylokernelmixture.h:151).  20 states only (IQHIP_ERR_UNSUPPORTED else). */
+int iqhip_set_mixture_model(iqhip_engine *e, int nclass, const int32_t *cat_class /* [ncat] */,
+                            const double *eval, const double *evec, const double *inv_evec,
+                            const double *rates /* [ncat] */, const double *props /* [ncat] */,
+                            int state_unknown, const double *tip_partial_lh);
+
 /* Execute a post-ordered list of node updates (children before parents) in ONE submission.
  * sum_scale[k] receives op k's own sum_scale (phylokernel.h:389,471: LOG_SCALING_THRESHOLD *
  * sum of ptn_freq over the patterns rescaled at this node); the caller keeps

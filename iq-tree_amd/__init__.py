@@ -30,6 +30,7 @@ IQHIP_SYMBOLS = [
     "iqhip_synchronize", "iqhip_fetch_scale_num", "iqhip_fetch_pattern_lh", "iqhip_fetch_partial",
     "iqhip_fetch_theta", "iqhip_upload_partial", "iqhip_timing_enable", "iqhip_timing_read",
     "iqhip_fetch_pattern_lh_scaled", "iqhip_set_boot_samples", "iqhip_rell", "iqhip_rell_async",
+    "iqhip_set_mixture_model",
 ]
 
 
@@ -140,6 +141,7 @@ def libiqhost():
     lib.iqhost_set_alignment.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_uint8), dp, dp]
     lib.iqhost_set_ascertainment.argtypes = [vp, C.c_int64, C.c_double]
     lib.iqhost_set_model.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp]
+    lib.iqhost_set_mixture_model.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), dp, dp, dp, dp, dp]
     lib.iqhost_set_mem_mode.argtypes = [vp, C.c_int]
     lib.iqhost_set_kernel.argtypes = [vp, C.c_int]
     lib.iqhost_attach_engine.argtypes = [vp, C.c_int]
@@ -274,12 +276,19 @@ class PhyloTree:
         self._chk(self.lib.iqhost_set_ascertainment(self.h, int(n_unobserved), float(nsites)))
 
     def set_model(self, model):
-        """model: object with eval, evec, inv_evec, rates, props (see synth.Model)."""
+        """model: object with eval, evec, inv_evec, rates, props (see synth.Model); a mixture model also
+        has nclass > 1 and cat_class (component -> eigen-system), its arrays concatenated per class."""
         a = [np.ascontiguousarray(x, dtype=np.float64) for x in
              (model.eval, model.evec, model.inv_evec, model.rates, model.props)]
         self.ncat = len(a[3])
         self.block = self.nstates * self.ncat
-        self._chk(self.lib.iqhost_set_model(self.h, self.ncat, *[_dptr(x) for x in a]))
+        nclass = int(getattr(model, "nclass", 1))
+        if nclass > 1:
+            cls = np.ascontiguousarray(model.cat_class, dtype=np.int32)
+            self._chk(self.lib.iqhost_set_mixture_model(self.h, nclass, self.ncat, cls.ctypes.data_as(C.POINTER(C.c_int)),
+                                                        *[_dptr(x) for x in a]))
+        else:
+            self._chk(self.lib.iqhost_set_model(self.h, self.ncat, *[_dptr(x) for x in a]))
 
     def set_mem_mode(self, lm):
         self._chk(self.lib.iqhost_set_mem_mode(self.h, lm))
@@ -490,7 +499,11 @@ class PhyloTree:
 
 class AttrDict(dict):
     """dict whose keys also read as attributes (so it can stand where a synth.Model is expected)."""
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
 
 
 def _mchk(lib, rc):

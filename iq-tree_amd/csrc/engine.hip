@@ -51,8 +51,8 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
                     "other counts use its scalar kernel)");
     if (nstates == 4 && !(ncat >= 1 && ncat <= 8 && ncat != 7))
         return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_create: 4-state path supports ncat in {1..6,8}");
-    if (nstates != 4 && ncat > 16)
-        return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_create: ncat must be <= 16");
+    if (nstates != 4 && ncat > (nstates == 20 ? 96 : 16))  // 20 states: (class, rate) components of mixtures
+        return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_create: ncat must be <= 16 (<= 96 components for 20 states)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(IQHIP_ERR_NO_DEVICE, "iqhip_create: no HIP device available");
@@ -66,8 +66,9 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     e->ntaxa = ntaxa;
     e->nptn = nptn;
     e->mfma = nstates != 4;
-    e->mfma_pipelined = ((nstates == 20 && (ncat == 4 || ncat == 1)) || (nstates == 64 && ncat == 1)) &&
-                        !getenv("IQHIP_MFMA_V1");
+    e->mfma_pipelined_ok = ((nstates == 20 && (ncat == 4 || ncat == 1)) || (nstates == 64 && ncat == 1)) &&
+                           !getenv("IQHIP_MFMA_V1");
+    e->mfma_pipelined = e->mfma_pipelined_ok;
     e->tile = e->mfma ? 16 : 64;
     e->block = nstates * ncat;
     e->nptn_pad = round_up(nptn, 64);
@@ -149,7 +150,7 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
     void *ptrs[] = {e->d_states, e->d_freq, e->d_invar, e->d_eval, e->d_evec, e->d_inv_evec,
                     e->d_rates, e->d_props, e->d_tip, e->d_ops, e->d_slab,
                     e->d_theta, e->d_pattern_lh, e->dummy.plh, e->dummy.sc, e->d_newton_partials,
-                    e->d_newton_barrier, e->d_ptn_scaled, e->d_boot};
+                    e->d_newton_barrier, e->d_ptn_scaled, e->d_boot, e->d_evalc, e->d_tipc, e->d_cls, e->d_img};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (e->h_ops) hipHostFree(e->h_ops);
@@ -312,29 +313,115 @@ extern "C" int iqhip_set_ascertainment(iqhip_engine *e, int64_t n_unobserved, do
     return IQHIP_OK;
 }
 
-extern "C" int iqhip_set_model(iqhip_engine *e, const double *eval, const double *evec,
-                               const double *inv_evec, const double *rates, const double *props,
-                               int state_unknown, const double *tip_partial_lh) {
-    if (!e || !eval || !evec || !inv_evec || !rates || !props || !tip_partial_lh)
+static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_class, const double *eval,
+                            const double *evec, const double *inv_evec, const double *rates, const double *props,
+                            int state_unknown, const double *tip /* [state][class][n] */) {
+    if (!e || !eval || !evec || !inv_evec || !rates || !props || !tip)
         return fail(IQHIP_ERR_INVALID, "null argument");
     if (state_unknown < e->n || state_unknown > (e->mfma ? 255 : 31))
         return fail(IQHIP_ERR_INVALID, "iqhip_set_model: state_unknown out of range");
     if (e->aln_set && state_unknown != e->state_unknown)
         return fail(IQHIP_ERR_INVALID, "iqhip_set_model: state_unknown changed after set_alignment");
+    if (nclass < 1 || nclass > e->ncat) return fail(IQHIP_ERR_INVALID, "bad number of mixture classes");
+    if (nclass > 1 && e->n != 20)
+        return fail(IQHIP_ERR_UNSUPPORTED, "mixture models are implemented for 20 states (matrix-core kernel) only");
+    std::vector<int> cls(e->ncat, 0);
+    if (nclass > 1) {
+        if (!cat_class) return fail(IQHIP_ERR_INVALID, "null argument");
+        for (int c = 0; c < e->ncat; c++) {
+            if (cat_class[c] < 0 || cat_class[c] >= nclass) return fail(IQHIP_ERR_INVALID, "category class out of range");
+            cls[c] = cat_class[c];
+        }
+    }
     HIPCHK(hipSetDevice(e->device));
-    const int n = e->n;
+    const int n = e->n, C = e->ncat;
     HIPCHK(hipStreamSynchronize(e->stream));  // previous work may still read the old model
+    // class 0 in the single-class arrays (4-state and pipelined kernels)
     HIPCHK(hipMemcpy(e->d_eval, eval, sizeof(double) * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_evec, evec, sizeof(double) * n * n, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->d_inv_evec, inv_evec, sizeof(double) * n * n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_rates, rates, sizeof(double) * e->ncat, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_props, props, sizeof(double) * e->ncat, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_tip, tip_partial_lh, sizeof(double) * (state_unknown + 1) * n,
-                     hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_rates, rates, sizeof(double) * C, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_props, props, sizeof(double) * C, hipMemcpyHostToDevice));
+    {
+        std::vector<double> tip0((size_t)(state_unknown + 1) * n);
+        for (int s = 0; s <= state_unknown; s++)
+            memcpy(&tip0[(size_t)s * n], &tip[((size_t)s * nclass) * n], sizeof(double) * n);
+        HIPCHK(hipMemcpy(e->d_tip, tip0.data(), sizeof(double) * tip0.size(), hipMemcpyHostToDevice));
+    }
+    // per-category expansions
+    std::vector<double> evalc((size_t)C * n), tipc((size_t)(state_unknown + 1) * C * n);
+    for (int c = 0; c < C; c++) memcpy(&evalc[(size_t)c * n], &eval[(size_t)cls[c] * n], sizeof(double) * n);
+    for (int s = 0; s <= state_unknown; s++)
+        for (int c = 0; c < C; c++)
+            memcpy(&tipc[((size_t)s * C + c) * n], &tip[((size_t)s * nclass + cls[c]) * n], sizeof(double) * n);
+    if (e->d_tipc) HIPCHK(hipFree(e->d_tipc));
+    e->d_tipc = nullptr;
+    if (!e->d_evalc) HIPCHK(dmalloc(&e->d_evalc, (size_t)C * n));
+    if (!e->d_cls) HIPCHK(hipMalloc((void **)&e->d_cls, sizeof(int) * C));
+    HIPCHK(dmalloc(&e->d_tipc, tipc.size()));
+    HIPCHK(hipMemcpy(e->d_evalc, evalc.data(), sizeof(double) * evalc.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_tipc, tipc.data(), sizeof(double) * tipc.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_cls, cls.data(), sizeof(int) * C, hipMemcpyHostToDevice));
+    if (e->d_img) HIPCHK(hipFree(e->d_img));
+    e->d_img = nullptr;
+    if (nclass > 1) {
+        // MFMA A-operand images of every class for k_traverse_mfma_mix20: [class][U16 | U4 | Ui16 | Ui4][s][lane]
+        // (16-row tile: row = lane & 15; 4-row tail: row = 16 + (lane & 3); k = 4s + (lane >> 4)), followed by
+        // the padded two-tile images [class][U | U^-1][m][s][lane] of the generic kernel (IQHIP_MIX_GENERIC)
+        const int MT = (n + 15) / 16, KS = n / 4;
+        const size_t mix_doubles = (size_t)nclass * 4 * KS * 64;
+        std::vector<double> img(mix_doubles + (size_t)nclass * 2 * MT * KS * 64, 0.0);
+        for (int m = 0; m < nclass; m++) {
+            const double *U = evec + (size_t)m * n * n, *Ui = inv_evec + (size_t)m * n * n;
+            for (int s = 0; s < KS; s++)
+                for (int l = 0; l < 64; l++) {
+                    const int k = 4 * s + (l >> 4), r16 = l & 15, r4 = 16 + (l & 3);
+                    double *b = &img[(size_t)m * 4 * KS * 64];
+                    b[(0 * KS + s) * 64 + l] = U[r16 * n + k];
+                    b[(2 * KS + s) * 64 + l] = Ui[r16 * n + k];
+                    if (r4 < n) {
+                        b[(1 * KS + s) * 64 + l] = U[r4 * n + k];
+                        b[(3 * KS + s) * 64 + l] = Ui[r4 * n + k];
+                    }
+                }
+            for (int t = 0; t < MT * KS * 64; t++) {
+                const int l = t & 63, ms = t >> 6, s = ms % KS, mt = ms / KS;
+                const int row = 16 * mt + (l & 15), k = 4 * s + (l >> 4);
+                if (row < n) {
+                    img[mix_doubles + ((size_t)m * 2 + 0) * MT * KS * 64 + t] = U[row * n + k];
+                    img[mix_doubles + ((size_t)m * 2 + 1) * MT * KS * 64 + t] = Ui[row * n + k];
+                }
+            }
+        }
+        e->img_generic_off = mix_doubles;
+        HIPCHK(dmalloc(&e->d_img, img.size()));
+        HIPCHK(hipMemcpy(e->d_img, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
+    }
+    // the pipelined kernels hold one eigen-system in registers / LDS: mixtures take the generic kernel,
+    // whose plans have a different canonical form -> drop the cached descriptors
+    const bool pipelined = e->mfma_pipelined_ok && nclass == 1;
+    if (pipelined != e->mfma_pipelined || nclass != e->nclass) {
+        e->mfma_pipelined = pipelined;
+        e->uploaded_plan.clear();
+        e->last_plan_version = 0;
+    }
+    e->nclass = nclass;
     e->state_unknown = state_unknown;
     e->model_set = true;
     e->theta_valid = false;
     return IQHIP_OK;
+}
+
+extern "C" int iqhip_set_model(iqhip_engine *e, const double *eval, const double *evec,
+                               const double *inv_evec, const double *rates, const double *props,
+                               int state_unknown, const double *tip_partial_lh) {
+    return set_model_common(e, 1, nullptr, eval, evec, inv_evec, rates, props, state_unknown, tip_partial_lh);
+}
+
+extern "C" int iqhip_set_mixture_model(iqhip_engine *e, int nclass, const int32_t *cat_class, const double *eval,
+                                       const double *evec, const double *inv_evec, const double *rates,
+                                       const double *props, int state_unknown, const double *tip_partial_lh) {
+    return set_model_common(e, nclass, cat_class, eval, evec, inv_evec, rates, props, state_unknown, tip_partial_lh);
 }
 
 // ---------------------------------------------------------------------------------------

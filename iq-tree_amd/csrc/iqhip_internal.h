@@ -122,6 +122,17 @@ struct iqhip_engine {
     double *d_slab = nullptr;   // wave partials [nvals][nwaves]
     int64_t slab_cap = 0;
     double *d_theta = nullptr, *d_pattern_lh = nullptr;
+    // Mixture models (phylokernelmixture.h, phylokernelmixrate.h): the ncat categories are (class, rate)
+    // components; category c uses eigen-system cat_class[c].  Per-category expansions for the kernels
+    // that are generic in (n, ncat): evalc[c][i], tipc[state][c][i]; per-class MFMA A images for the
+    // mixture traversal kernel.  A plain model is the one-class case.
+    int nclass = 1;
+    double *d_evalc = nullptr;   // [ncat][n]
+    double *d_tipc = nullptr;    // [state_unknown+1][ncat][n]
+    int *d_cls = nullptr;        // [ncat]
+    double *d_img = nullptr;     // mixture A images: mix20 layout, then the generic kernel's (engine.hip)
+    size_t img_generic_off = 0;
+    bool mfma_pipelined_ok = false;  // (n, ncat) has a pipelined instantiation (used when nclass == 1)
     // UFBoot / RELL (kernels_rell.hip): scaled per-pattern lnL and the bootstrap sample matrix
     double *d_ptn_scaled = nullptr;
     float *d_boot = nullptr;  // [nboot][nptn_pad], zero padded

@@ -53,6 +53,11 @@ struct TravMArgs {
     const double *invar;
     const double *eval;
     const double *rates;
+    const double *evalc;    // [ncat][n] eigenvalues of each category's class
+    const double *tipc;     // [state][ncat][n]
+    const int *cls;         // [ncat] class of each category (mixtures)
+    const double *img;      // mixture A images, k_traverse_mfma_mix20 layout [class][U16|U4|Ui16|Ui4][KS][64]
+    const double *img_generic;  // ... generic kernel layout [class][U|U^-1][MT][KS][64]
     double *slab;           // [nvals][nwaves]
     int64_t ntiles;         // tiles of 16 patterns
     int64_t nptn;
@@ -68,7 +73,9 @@ struct TravMArgs {
 template <int KS>
 __device__ __forceinline__ int aidx(int m, int s, int lane) { return (m * KS + s) * 64 + lane; }
 
-template <int N, int WG>
+// MIX: mixture model -- category c takes its A operands (U, U^-1 of class cls[c]) from the per-class images
+// in global memory (L2-resident) and its tip vectors from tipc[state][c][:] instead of the LDS copies.
+template <int N, int WG, bool MIX>
 __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
     constexpr int MT = (N + 15) / 16;  // M tiles (rows padded to 16)
     constexpr int KS = N / 4;          // k-steps of 4
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
             const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B;
             const CONST_AS DevOp &d = as_const(A.ops)[k + o];
             const double len = child ? d.right_len : d.left_len;
-            sReg[(child ? d.lds_right : d.lds_left) + e] = exp(A.eval[e % N] * (A.rates[e / N] * len));
+            sReg[(child ? d.lds_right : d.lds_left) + e] = exp(A.evalc[e] * (A.rates[e / N] * len));
         }
         __syncthreads();
         if (!active) { k += kn; continue; }
@@ -130,6 +137,12 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
             double *dst = op.dst + tbase;
             double lmax = 0.0;
             for (int c = 0; c < C; c++) {
+                // A operands of this category's class
+                const double *aU = sU, *aUi = sUi;
+                if (MIX) {
+                    aU = A.img_generic + (size_t)as_const(A.cls)[c] * 2 * MT * KS * 64;
+                    aUi = aU + MT * KS * 64;
+                }
                 v4f64 YL[MT], YR[MT];
 #pragma unroll
                 for (int m = 0; m < MT; m++) { YL[m] = (v4f64){0, 0, 0, 0}; YR[m] = (v4f64){0, 0, 0, 0}; }
@@ -139,12 +152,14 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
                     double bl, br;
                     if (leafL) {
                         // tip_partial_lh[state][i] = U^-1[i][state] for state < N (phylotreesse.cpp:464-471)
-                        bl = sL < N ? sUi[aidx<KS>(i >> 4, sL >> 2, (sL & 3) * 16 + (i & 15))] : sTipx[(sL - N) * N + i];
+                        if (MIX) bl = A.tipc[((size_t)sL * C + c) * N + i];
+                        else bl = sL < N ? sUi[aidx<KS>(i >> 4, sL >> 2, (sL & 3) * 16 + (i & 15))] : sTipx[(sL - N) * N + i];
                     } else {
                         bl = vL[(size_t)c * N * 16 + s * 64 + lane];
                     }
                     if (leafR) {
-                        br = sR < N ? sUi[aidx<KS>(i >> 4, sR >> 2, (sR & 3) * 16 + (i & 15))] : sTipx[(sR - N) * N + i];
+                        if (MIX) br = A.tipc[((size_t)sR * C + c) * N + i];
+                        else br = sR < N ? sUi[aidx<KS>(i >> 4, sR >> 2, (sR & 3) * 16 + (i & 15))] : sTipx[(sR - N) * N + i];
                     } else {
                         br = vR[(size_t)c * N * 16 + s * 64 + lane];
                     }
@@ -152,7 +167,7 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
                     br *= exR[c * N + i];
 #pragma unroll
                     for (int m = 0; m < MT; m++) {
-                        const double a = sU[aidx<KS>(m, s, lane)];
+                        const double a = aU[aidx<KS>(m, s, lane)];
                         YL[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bl, YL[m], 0, 0, 0);
                         YR[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, br, YR[m], 0, 0, 0);
                     }
@@ -175,7 +190,7 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
                     const double bt = T[s >> 2][s & 3];  // accumulator layout == B layout of k-step s
 #pragma unroll
                     for (int m = 0; m < MT; m++)
-                        O[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(sUi[aidx<KS>(m, s, lane)], bt, O[m], 0, 0, 0);
+                        O[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aUi[aidx<KS>(m, s, lane)], bt, O[m], 0, 0, 0);
                 }
 #pragma unroll
                 for (int m = 0; m < MT; m++)
@@ -486,20 +501,171 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
     }
 }
 
-template <int N>
+template <int N, bool MIX>
 static hipError_t launch_trav_m(iqhip_engine *e, TravMArgs &A) {
     constexpr int MT = (N + 15) / 16, KS = N / 4, WG = 256;
     const int nx = e->state_unknown + 1 - N;
     const size_t lds = (size_t)(2 * MT * KS * 64 + nx * N + e->plan_lds_doubles) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma<N, WG>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma<N, WG, MIX>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     A.ngroups = (int)((A.ntiles + 3) / 4);
     const int grid = A.ngroups * A.nsegs_launch;
-    hipLaunchKernelGGL((k_traverse_mfma<N, WG>), dim3(grid), dim3(WG), lds, e->stream, A);
+    hipLaunchKernelGGL((k_traverse_mfma<N, WG, MIX>), dim3(grid), dim3(WG), lds, e->stream, A);
+    return hipGetLastError();
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Mixture models (phylokernelmixture.h:20-460, phylokernelmixrate.h:22-450), 20 states.  The block of a
+// pattern is C = (class, rate) components x 20 doubles -- too large for the register-resident scheme of
+// k_traverse_mfma2 -- so both children are streamed from memory, one component ahead of the one being
+// multiplied.  The A fragments (U, U^-1 of the component's class: 16-row tile + 4-row tail, 20 doubles)
+// are re-read from the per-class images only when the class changes (block order [class][rate]).
+// ---------------------------------------------------------------------------------------
+template <int WG>
+__global__ __launch_bounds__(WG, 2) void k_traverse_mfma_mix20(const TravMArgs A) {
+    constexpr int N = 20, KS = 5, WPB = WG / 64;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *sReg = smem;  // per (op, child) exponentials [C*N] of the chunk
+    const int C = A.ncat;
+    const int B = C * N;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int seg = (int)blockIdx.x / A.ngroups;  // scalar
+    const int k_begin = as_const(A.segs)[2 * seg], k_end = k_begin + as_const(A.segs)[2 * seg + 1];
+    const int64_t tile = (int64_t)((int)blockIdx.x - seg * A.ngroups) * WPB + wave;
+    const bool active = tile < A.ntiles;
+    const int64_t tl = active ? tile : 0;
+    const int p = lane & 15, g = lane >> 4;
+    const int64_t ptn = tl * 16 + p;
+    const size_t tbase = (size_t)tl * 16 * B;  // doubles
+    const double freq = A.freq[ptn];
+    const double invar = A.invar[ptn];
+    const CONST_AS DevOp *ops = as_const(A.ops);
+    const CONST_AS int *cls = as_const(A.cls);
+
+    double aU[KS], aU4[KS], aUi[KS], aUi4[KS];
+    int cur_class = -1;
+
+    int k = k_begin;
+    while (k < k_end) {
+        const int kn = ops[k].chunk_nops;
+        __syncthreads();
+        for (int t = threadIdx.x; t < kn * 2 * B; t += WG) {
+            const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B;
+            const CONST_AS DevOp &d = ops[k + o];
+            const double len = child ? d.right_len : d.left_len;
+            sReg[(child ? d.lds_right : d.lds_left) + e] = exp(A.evalc[e] * (A.rates[e / N] * len));
+        }
+        __syncthreads();
+        if (!active) { k += kn; continue; }
+
+        for (int kk = 0; kk < kn; kk++, k++) {
+            const CONST_AS DevOp &op = ops[k];
+            const bool leafL = op.left_kind == CHILD_LEAF, leafR = op.right_kind == CHILD_LEAF;
+            const double *exL = sReg + op.lds_left, *exR = sReg + op.lds_right;
+            int sc = 0, sL = 0, sR = 0;
+            if (leafL) sL = op.sl[ptn]; else if (g == 0) sc += op.pf_sc[ptn];
+            if (leafR) sR = op.sr[ptn]; else if (g == 0) sc += op.ld_sc[ptn];
+            const bool unkL = leafL && sL == A.state_unknown, unkR = leafR && sR == A.state_unknown;
+            // component c of a child: 5 k-step slices -- a vector in memory, or this pattern's tip vector
+            const double *srcL = leafL ? A.tipc + (size_t)sL * B + g : op.pf + tbase + lane;
+            const double *srcR = leafR ? A.tipc + (size_t)sR * B + g : op.ld + tbase + lane;
+            const int strideL = leafL ? N : N * 16, stepL = leafL ? 4 : 64;  // per component / per k-step
+            const int strideR = leafR ? N : N * 16, stepR = leafR ? 4 : 64;
+            double *dst = op.dst + tbase;
+            double lmax = 0.0;
+            double nl[KS], nr[KS];
+#pragma unroll
+            for (int s = 0; s < KS; s++) { nl[s] = srcL[s * stepL]; nr[s] = srcR[s * stepR]; }
+            for (int c = 0; c < C; c++) {
+                double bl[KS], br[KS];
+#pragma unroll
+                for (int s = 0; s < KS; s++) { bl[s] = nl[s]; br[s] = nr[s]; }
+                {   // request component c+1 (the last request of an op re-reads component C-1: harmless)
+                    const int cn = (c + 1 < C) ? c + 1 : c;
+#pragma unroll
+                    for (int s = 0; s < KS; s++) {
+                        nl[s] = srcL[(size_t)cn * strideL + s * stepL];
+                        nr[s] = srcR[(size_t)cn * strideR + s * stepR];
+                    }
+                }
+                const int m = cls[c];
+                if (m != cur_class) {  // wave-uniform
+                    const double *im = A.img + (size_t)m * 4 * KS * 64 + lane;
+#pragma unroll
+                    for (int s = 0; s < KS; s++) {
+                        aU[s] = im[s * 64];
+                        aU4[s] = im[(KS + s) * 64];
+                        aUi[s] = im[(2 * KS + s) * 64];
+                        aUi4[s] = im[(3 * KS + s) * 64];
+                    }
+                    cur_class = m;
+                }
+                v4f64 YL = {0, 0, 0, 0}, YR = {0, 0, 0, 0};
+                double yl4 = 0.0, yr4 = 0.0;
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    const int i = 4 * s + g;
+                    const double xl = bl[s] * exL[c * N + i];
+                    const double xr = br[s] * exR[c * N + i];
+                    YL = __builtin_amdgcn_mfma_f64_16x16x4f64(aU[s], xl, YL, 0, 0, 0);
+                    YR = __builtin_amdgcn_mfma_f64_16x16x4f64(aU[s], xr, YR, 0, 0, 0);
+                    yl4 = __builtin_amdgcn_mfma_f64_4x4x4f64(aU4[s], xl, yl4, 0, 0, 0);
+                    yr4 = __builtin_amdgcn_mfma_f64_4x4x4f64(aU4[s], xr, yr4, 0, 0, 0);
+                }
+                double T[KS];
+#pragma unroll
+                for (int r = 0; r < 4; r++) T[r] = (unkL ? 1.0 : YL[r]) * (unkR ? 1.0 : YR[r]);
+                T[4] = (unkL ? 1.0 : yl4) * (unkR ? 1.0 : yr4);
+                v4f64 O = {0, 0, 0, 0};
+                double o4 = 0.0;
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    O = __builtin_amdgcn_mfma_f64_16x16x4f64(aUi[s], T[s], O, 0, 0, 0);
+                    o4 = __builtin_amdgcn_mfma_f64_4x4x4f64(aUi4[s], T[s], o4, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    dst[(size_t)(c * N + 4 * r + g) * 16 + p] = O[r];
+                    lmax = fmax(lmax, fabs(O[r]));
+                }
+                dst[(size_t)(c * N + 16 + g) * 16 + p] = o4;
+                lmax = fmax(lmax, fabs(o4));
+            }
+            lmax = fmax(lmax, __shfl_xor(lmax, 16, 64));
+            lmax = fmax(lmax, __shfl_xor(lmax, 32, 64));
+            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0);
+            double my_scale = 0.0;
+            if (__any(do_scale)) {
+                if (do_scale) {
+                    for (int e = g; e < B; e += 4) dst[(size_t)e * 16 + p] *= kScalingThresholdInv;
+                    sc += 1;
+                    if (g == 0 && ptn < A.nptn) my_scale = kLogScalingThreshold * freq;
+                }
+            }
+            if (g == 0) op.dst_sc[ptn] = (int16_t)sc;
+            const double ws = wave_sum_m(my_scale);
+            if (lane == 0) A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
+        }
+    }
+}
+
+static hipError_t launch_trav_mix20(iqhip_engine *e, TravMArgs &A) {
+    constexpr int WG = 256;
+    const size_t lds = (size_t)e->plan_lds_doubles * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma_mix20<WG>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    A.ngroups = (int)((A.ntiles + 3) / 4);
+    hipLaunchKernelGGL((k_traverse_mfma_mix20<WG>), dim3((unsigned)(A.ngroups * A.nsegs_launch)), dim3(WG), lds, e->stream, A);
     return hipGetLastError();
 }
 
@@ -536,6 +702,11 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs
     A.invar = e->d_invar;
     A.eval = e->d_eval;
     A.rates = e->d_rates;
+    A.evalc = e->d_evalc;
+    A.tipc = e->d_tipc;
+    A.cls = e->d_cls;
+    A.img = e->d_img;
+    A.img_generic = e->d_img ? e->d_img + e->img_generic_off : nullptr;
     A.slab = e->d_slab;
     A.ntiles = e->ntiles;
     A.nptn = e->nptn;
@@ -552,8 +723,10 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs
         return hipErrorInvalidValue;
     }
     switch (e->n) {
-        case 20: return launch_trav_m<20>(e, A);
-        case 64: return launch_trav_m<64>(e, A);
+        case 20:
+            if (e->nclass > 1) return getenv("IQHIP_MIX_GENERIC") ? launch_trav_m<20, true>(e, A) : launch_trav_mix20(e, A);
+            return launch_trav_m<20, false>(e, A);
+        case 64: return launch_trav_m<64, false>(e, A);
         default: return hipErrorInvalidValue;
     }
 }
@@ -596,7 +769,7 @@ __global__ __launch_bounds__(256) void k_stream_mfma(const StreamMArgs A) {
     if (MODE != 1) {
         for (int t = threadIdx.x; t < B; t += 256) {
             const int c = t / N, i = t - c * N;
-            const double cof = A.eval[i] * A.rates[c];
+            const double cof = A.eval[t] * A.rates[c];  // eval: per-category expansion [ncat][n]
             const double v = exp(cof * A.len) * A.props[c];
             s_v0[t] = v;
             s_v1[t] = cof * v;
@@ -616,10 +789,10 @@ __global__ __launch_bounds__(256) void k_stream_mfma(const StreamMArgs A) {
         const double *bv = A.br.b + tbase;
         const bool leaf = A.br.a_kind == CHILD_LEAF;
         const int s = leaf ? A.br.a_states[ptn] : 0;
-        const double *av = leaf ? A.tip + (size_t)s * N : A.br.a + tbase;
+        const double *av = leaf ? A.tip + (size_t)s * B : A.br.a + tbase;  // tip: [state][ncat][n]
         for (int e = g; e < B; e += 4) {
             const double b = bv[(size_t)e * 16 + p];
-            const double a = leaf ? av[e % N] : av[(size_t)e * 16 + p];
+            const double a = leaf ? av[e] : av[(size_t)e * 16 + p];
             if (MODE == 1) A.theta[tbase + (size_t)e * 16 + p] = a * b;
             else lh = fma(s_v0[e] * a, b, lh);
         }
@@ -690,8 +863,8 @@ __global__ __launch_bounds__(256) void k_stream_mfma(const StreamMArgs A) {
 hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, double len, int nwaves) {
     StreamMArgs A;
     if (br) A.br = *br; else A.br = DevBranch{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.0};
-    A.tip = e->d_tip;
-    A.eval = e->d_eval;
+    A.tip = e->d_tipc;
+    A.eval = e->d_evalc;
     A.rates = e->d_rates;
     A.props = e->d_props;
     A.freq = e->d_freq;

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_newton(const NewtonArgs A) {
     auto eval_at = [&](double x, double &f, double &df) {
         for (int t = threadIdx.x; t < B; t += 256) {
             const int c = t / A.n, i = t - c * A.n;
-            const double cof = A.eval[i] * A.rates[c];
+            const double cof = A.eval[t] * A.rates[c];  // eval: per-category expansion [ncat][n]
             const double v = exp(cof * x) * A.props[c];
             s_v0[t] = v;
             s_v1[t] = cof * v;
@@ -205,7 +205,7 @@ hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, d
                          double *out) {
     NewtonArgs A;
     A.theta = e->d_theta;
-    A.eval = e->d_eval;
+    A.eval = e->d_evalc;
     A.rates = e->d_rates;
     A.props = e->d_props;
     A.freq = e->d_freq;

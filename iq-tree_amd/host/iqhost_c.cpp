@@ -61,6 +61,10 @@ int iqhost_set_model(void *h, int ncat, const double *eval, const double *evec, 
                      const double *rates, const double *props) {
     IQHOST_TRY(((PhyloTree *)h)->setModel(ncat, eval, evec, inv_evec, rates, props));
 }
+int iqhost_set_mixture_model(void *h, int nclass, int ncat, const int *cat_class, const double *eval, const double *evec,
+                             const double *inv_evec, const double *rates, const double *props) {
+    IQHOST_TRY(((PhyloTree *)h)->setMixtureModel(nclass, ncat, cat_class, eval, evec, inv_evec, rates, props));
+}
 int iqhost_set_mem_mode(void *h, int lm) {
     IQHOST_TRY(((PhyloTree *)h)->lh_mem_save = (LhMemSave)lm);
 }

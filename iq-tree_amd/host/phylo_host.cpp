@@ -276,50 +276,63 @@ void PhyloTree::setAscertainment(int64_t n_unobs, double nsites) {
 
 void PhyloTree::setModel(int ncat_, const double *eval, const double *evec, const double *inv_evec,
                          const double *rates, const double *props) {
+    setMixtureModel(1, ncat_, nullptr, eval, evec, inv_evec, rates, props);
+}
+
+void PhyloTree::setMixtureModel(int nclass, int ncat_, const int *cat_class, const double *eval, const double *evec,
+                                const double *inv_evec, const double *rates, const double *props) {
     if (num_states <= 0) throw std::runtime_error("setAlignment first");
     if (engine && ncat_ != ncat) throw std::runtime_error("ncat cannot change after attachEngine");
+    if (nclass < 1 || (nclass > 1 && !cat_class)) throw std::runtime_error("bad mixture description");
     const int n = num_states;
     ncat = ncat_;
-    m_eval.assign(eval, eval + n);
-    m_evec.assign(evec, evec + n * n);
-    m_inv_evec.assign(inv_evec, inv_evec + n * n);
+    nmixture = nclass;
+    m_eval.assign(eval, eval + (size_t)nclass * n);
+    m_evec.assign(evec, evec + (size_t)nclass * n * n);
+    m_inv_evec.assign(inv_evec, inv_evec + (size_t)nclass * n * n);
     m_rates.assign(rates, rates + ncat);
     m_props.assign(props, props + ncat);
+    m_cat_class.assign(ncat, 0);
+    if (nclass > 1) m_cat_class.assign(cat_class, cat_class + ncat);
     computeTipPartialLikelihood();
     inputs_dirty = true;
     theta_computed = false;
 }
 
+// phylotreesse.cpp:359-529; for mixtures tip_partial_lh[state][class][i] (:395-458)
 void PhyloTree::computeTipPartialLikelihood() {
-    const int n = num_states;
-    tip_partial_lh.assign((size_t)(STATE_UNKNOWN + 1) * n, 0.0);
-    const double *inv_evec = m_inv_evec.data();
-    for (int state = 0; state < n; state++)
-        for (int i = 0; i < n; i++) tip_partial_lh[state * n + i] = inv_evec[i * n + state];
-    for (int i = 0; i < n; i++) {  // unknown character: sum over all states
-        double lh_unknown = 0.0;
-        for (int x = 0; x < n; x++) lh_unknown += inv_evec[i * n + x];
-        tip_partial_lh[STATE_UNKNOWN * n + i] = lh_unknown;
-    }
-    if (seq_type == SEQ_DNA && n == 4) {
-        for (int state = 4; state < 18; state++) {  // IUPAC ambiguity = bitmask state-3
-            const int cstate = state - n + 1;
-            for (int i = 0; i < n; i++) {
-                double lh = 0.0;
-                for (int x = 0; x < n; x++)
-                    if (cstate & (1 << x)) lh += inv_evec[i * n + x];
-                tip_partial_lh[state * n + i] = lh;
-            }
+    const int n = num_states, M = nmixture;
+    tip_partial_lh.assign((size_t)(STATE_UNKNOWN + 1) * M * n, 0.0);
+    for (int m = 0; m < M; m++) {
+        const double *inv_evec = m_inv_evec.data() + (size_t)m * n * n;
+        auto tip = [&](int state) { return &tip_partial_lh[((size_t)state * M + m) * n]; };
+        for (int state = 0; state < n; state++)
+            for (int i = 0; i < n; i++) tip(state)[i] = inv_evec[i * n + state];
+        for (int i = 0; i < n; i++) {  // unknown character: sum over all states
+            double lh_unknown = 0.0;
+            for (int x = 0; x < n; x++) lh_unknown += inv_evec[i * n + x];
+            tip(STATE_UNKNOWN)[i] = lh_unknown;
         }
-    } else if (seq_type == SEQ_PROTEIN && n == 20) {
-        const int ambi_aa[3] = {4 + 8, 32 + 64, 512 + 1024};  // B, Z, U
-        for (int k = 0; k < 3; k++)
-            for (int i = 0; i < n; i++) {
-                double lh = 0.0;
-                for (int x = 0; x < 11; x++)
-                    if (ambi_aa[k] & (1 << x)) lh += inv_evec[i * n + x];
-                tip_partial_lh[(20 + k) * n + i] = lh;
+        if (seq_type == SEQ_DNA && n == 4) {
+            for (int state = 4; state < 18; state++) {  // IUPAC ambiguity = bitmask state-3
+                const int cstate = state - n + 1;
+                for (int i = 0; i < n; i++) {
+                    double lh = 0.0;
+                    for (int x = 0; x < n; x++)
+                        if (cstate & (1 << x)) lh += inv_evec[i * n + x];
+                    tip(state)[i] = lh;
+                }
             }
+        } else if (seq_type == SEQ_PROTEIN && n == 20) {
+            const int ambi_aa[3] = {4 + 8, 32 + 64, 512 + 1024};  // B, Z, U
+            for (int k = 0; k < 3; k++)
+                for (int i = 0; i < n; i++) {
+                    double lh = 0.0;
+                    for (int x = 0; x < 11; x++)
+                        if (ambi_aa[k] & (1 << x)) lh += inv_evec[i * n + x];
+                    tip(20 + k)[i] = lh;
+                }
+        }
     }
 }
 
@@ -340,9 +353,15 @@ void PhyloTree::attachEngine(int device) {
 
 void PhyloTree::pushInputs() {
     if (!engine || !inputs_dirty) return;
-    check(iqhip_set_model(engine, m_eval.data(), m_evec.data(), m_inv_evec.data(), m_rates.data(),
-                          m_props.data(), STATE_UNKNOWN, tip_partial_lh.data()),
-          "iqhip_set_model");
+    if (nmixture > 1)
+        check(iqhip_set_mixture_model(engine, nmixture, m_cat_class.data(), m_eval.data(), m_evec.data(),
+                                      m_inv_evec.data(), m_rates.data(), m_props.data(), STATE_UNKNOWN,
+                                      tip_partial_lh.data()),
+              "iqhip_set_mixture_model");
+    else
+        check(iqhip_set_model(engine, m_eval.data(), m_evec.data(), m_inv_evec.data(), m_rates.data(),
+                              m_props.data(), STATE_UNKNOWN, tip_partial_lh.data()),
+              "iqhip_set_model");
     check(iqhip_set_alignment(engine, aln_states.data(), ptn_freq.data(), ptn_invar.data()),
           "iqhip_set_alignment");
     check(iqhip_set_ascertainment(engine, n_unobserved, asc_nsites), "iqhip_set_ascertainment");

@@ -100,6 +100,12 @@ public:
     double asc_nsites = 0.0;
     void setModel(int ncat, const double *eval, const double *evec, const double *inv_evec,
                   const double *rates, const double *props);
+    // Mixture models (ModelMixture; phylokernelmixture.h / phylokernelmixrate.h): ncat_ components in the
+    // reference's block order [class][rate], component q on eigen-system cat_class[q]; eval / evec /
+    // inv_evec are the nclass systems concatenated, props[q] = class weight x category proportion
+    void setMixtureModel(int nclass, int ncat, const int *cat_class, const double *eval, const double *evec,
+                         const double *inv_evec, const double *rates, const double *props);
+    int nmixture = 1;
     int num_states = 0, ncat = 0, STATE_UNKNOWN = 0;
     SeqType seq_type = SEQ_DNA;
     int64_t nptn = 0;
@@ -208,6 +214,7 @@ private:
     uint64_t nni_keys[6] = {0, 0, 0, 0, 0, 0};  // nni_partial_lh scratch (phylotree.cpp:852-860)
     std::vector<uint8_t> aln_states;
     std::vector<double> ptn_freq, ptn_invar, m_eval, m_evec, m_inv_evec, m_rates, m_props;
+    std::vector<int> m_cat_class;
     std::vector<PhyloNeighbor *> all_neighbors;
     void freeTree();
 };

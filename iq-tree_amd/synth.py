@@ -246,3 +246,57 @@ def make_workload(ntaxa, npatterns, model, seed, missing_frac=0.0, state_unknown
             return nwk, np.ascontiguousarray(pat[:, :npatterns]), freq[:npatterns].copy()
         nsites = int(nsites * 1.5)
     raise RuntimeError("could not reach the requested number of distinct patterns")
+
+
+# -------------------------------------------------------------------------------------------
+# mixture models (ModelMixture: phylokernelmixture.h / phylokernelmixrate.h)
+# -------------------------------------------------------------------------------------------
+
+class MixtureModel:
+    """(class, rate) components in the reference's block order [class][rate]: component q uses the
+    eigen-system of class cat_class[q]; eval / evec / inv_evec are the per-class arrays concatenated;
+    props[q] = class weight x category proportion.  `classes` are the plain per-class models (with the
+    component weights of that class as props) for an independent evaluation."""
+
+    def __init__(self, classes, cat_class, rates, props, name=""):
+        self.classes = classes
+        self.nclass = len(classes)
+        self.nstates = classes[0].nstates
+        self.cat_class = np.ascontiguousarray(cat_class, dtype=np.int32)
+        self.eval = np.concatenate([m.eval for m in classes])
+        self.evec = np.concatenate([m.evec for m in classes])
+        self.inv_evec = np.concatenate([m.inv_evec for m in classes])
+        self.rates = np.ascontiguousarray(rates, dtype=np.float64)
+        self.props = np.ascontiguousarray(props, dtype=np.float64)
+        self.ncat = len(self.rates)
+        self.freqs = classes[0].freqs
+        self.Q = classes[0].Q
+        self.pinvar = 0.0
+        self.name = name
+
+
+def mixture_model(n, nclass, seed, alpha=0.9, ncat=4, fused=False):
+    """Profile mixture (C10..C60 style: shared exchangeabilities, per-class frequencies) x discrete Gamma,
+    or, fused=True, one rate per class (LG4X style, phylokernelmixrate.h): ncomp = nclass."""
+    rng = np.random.default_rng(seed)
+    R = rng.gamma(shape=1.0, scale=1.0, size=(n, n)) + 0.05
+    w = rng.dirichlet(np.full(nclass, 8.0))
+    if fused:
+        r = rng.gamma(shape=2.0, scale=0.5, size=nclass) + 0.05
+        r = r / (w * r).sum()                     # mean rate 1
+        rates, props, cat_class = r, w, np.arange(nclass)
+        per_class = [(np.array([r[m]]), np.array([w[m]])) for m in range(nclass)]
+    else:
+        g = discrete_gamma_rates(alpha, ncat)
+        rates = np.tile(g, nclass)
+        props = np.repeat(w, ncat) / ncat
+        cat_class = np.repeat(np.arange(nclass), ncat)
+        per_class = [(g, np.full(ncat, w[m] / ncat)) for m in range(nclass)]
+    classes = []
+    for m in range(nclass):
+        f = rng.dirichlet(np.full(n, 3.0))
+        f = np.maximum(f, 2e-3)
+        base = reversible_model(R, f, None, 1, 0.0)
+        classes.append(Model(base.Q, base.freqs, base.eval, base.evec, base.inv_evec, per_class[m][0], per_class[m][1],
+                             0.0, "class%d" % m))
+    return MixtureModel(classes, cat_class, rates, props, name="MIX%d%s" % (nclass, "fused" if fused else "+G%d" % ncat))

@@ -59,6 +59,19 @@ double oracle_dot4(const double *a, const double *b, int n) { return dot4(a, b, 
 double oracle_exp(double x) { return exp(x); }
 double oracle_log(double x) { return log(x); }
 /* threads used by the pattern loop of oracle_partial_update (1 without OpenMP) */
+/* Mixture models (phylokernelmixture.h:20-460, phylokernelmixrate.h:22-450): the `ncat` categories of every
+ * function below are (class, rate) components; component c uses the eigen-system of class CLS(c).  eval /
+ * evec / inv_evec are then the per-class arrays concatenated and tip is [state][class][n]
+ * (phylokernelmixture.h:151).  One class (the default) is the plain model. */
+static int g_nclass = 1;
+static int g_cat_class[512];
+#define CLS(c) (g_nclass > 1 ? g_cat_class[(c)] : 0)
+#define TIPIDX(e) ((size_t)CLS((e) / n) * n + (e) % n)
+void oracle_set_mixture(int nclass, const int *cat_class, int ncat) {
+    g_nclass = nclass > 1 ? nclass : 1;
+    for (int c = 0; c < ncat && c < 512; c++) g_cat_class[c] = (nclass > 1) ? cat_class[c] : 0;
+}
+
 int oracle_set_threads(int n) {
 #ifdef _OPENMP
     if (n > 0) omp_set_num_threads(n);
@@ -111,9 +124,10 @@ void oracle_echild(int n, int ncat, const double *eval, const double *evec,
                    const double *rates, double len, double *E) {
     for (int c = 0; c < ncat; c++) {
         double l = rates[c] * len;
+        const double *ev = evec + (size_t)CLS(c) * n * n, *el = eval + (size_t)CLS(c) * n;
         for (int x = 0; x < n; x++)
             for (int i = 0; i < n; i++)
-                E[(size_t)c * n * n + x * n + i] = evec[x * n + i] * exp(eval[i] * l);
+                E[(size_t)c * n * n + x * n + i] = ev[x * n + i] * exp(el[i] * l);
     }
 }
 
@@ -126,7 +140,7 @@ void oracle_tip_table(int n, int ncat, int state_unknown, const double *E,
         for (int c = 0; c < ncat; c++)
             for (int x = 0; x < n; x++)
                 table[state * block + c * n + x] =
-                    dot4(&E[(size_t)c * n * n + x * n], &tip[state * n], n);
+                    dot4(&E[(size_t)c * n * n + x * n], &tip[((size_t)state * g_nclass + CLS(c)) * n], n);
     for (size_t x = 0; x < block; x++) table[state_unknown * block + x] = 1.0;
 }
 
@@ -177,7 +191,7 @@ static inline double update_one_pattern(int n, int ncat, size_t block, size_t pt
             for (int c = 0; c < ncat; c++) {
                 __m256d a = tl ? _mm256_loadu_pd(tl + c * 4) : mat4_vec(EL + c * 16, _mm256_loadu_pd(pl + c * 4));
                 __m256d b = tr ? _mm256_loadu_pd(tr + c * 4) : mat4_vec(ER + c * 16, _mm256_loadu_pd(pr + c * 4));
-                __m256d r = mat4_vec(inv_evec, _mm256_mul_pd(a, b));
+                __m256d r = mat4_vec(inv_evec + (size_t)CLS(c) * 16, _mm256_mul_pd(a, b));
                 _mm256_storeu_pd(out + c * 4, r);
                 vmax = _mm256_max_pd(vmax, _mm256_and_pd(r, absmask));
             }
@@ -193,7 +207,7 @@ static inline double update_one_pattern(int n, int ncat, size_t block, size_t pt
                 tmp[x] = a * b;
             }
             for (int i = 0; i < n; i++) {
-                double r = dot4(tmp, &inv_evec[i * n], n);
+                double r = dot4(tmp, &inv_evec[(size_t)CLS(c) * n * n + i * n], n);
                 out[c * n + i] = r;
                 double ar = fabs(r);
                 if (ar > lh_max) lh_max = ar;
@@ -271,7 +285,7 @@ static void branch_val(int n, int ncat, const double *eval, const double *rates,
                        const double *props, double len, double *val) {
     for (int c = 0; c < ncat; c++) {
         double l = rates[c] * len;
-        for (int i = 0; i < n; i++) val[c * n + i] = exp(eval[i] * l) * props[c];
+        for (int i = 0; i < n; i++) val[c * n + i] = exp(eval[(size_t)CLS(c) * n + i] * l) * props[c];
     }
 }
 
@@ -303,11 +317,11 @@ double oracle_branch_lnl(int n, int ncat, size_t nptn, const double *eval,
         const double *b = node_plh + ptn * block;
         double l[4];
         if (dad_states) {
-            const double *t = tip + (size_t)dad_states[ptn] * n;
-            for (int k = 0; k < 4; k++) l[k] = (val[k] * t[k % n]) * b[k];
+            const double *t = tip + (size_t)dad_states[ptn] * n * g_nclass;
+            for (int k = 0; k < 4; k++) l[k] = (val[k] * t[TIPIDX(k)]) * b[k];
             for (size_t i = 4; i < block; i += 4)
                 for (int k = 0; k < 4; k++)
-                    l[k] = (val[i + k] * t[(i + k) % n]) * b[i + k] + l[k];
+                    l[k] = (val[i + k] * t[TIPIDX(i + k)]) * b[i + k] + l[k];
         } else {
             const double *a = dad_plh + ptn * block;
             for (int k = 0; k < 4; k++) l[k] = 0.0;
@@ -342,8 +356,8 @@ void oracle_theta(int n, int ncat, size_t nptn, const double *tip,
         const double *b = node_plh + ptn * block;
         double *th = theta + ptn * block;
         if (dad_states) {
-            const double *t = tip + (size_t)dad_states[ptn] * n;
-            for (size_t i = 0; i < block; i++) th[i] = t[i % n] * b[i];
+            const double *t = tip + (size_t)dad_states[ptn] * n * g_nclass;
+            for (size_t i = 0; i < block; i++) th[i] = t[TIPIDX(i)] * b[i];
         } else {
             const double *a = dad_plh + ptn * block;
             for (size_t i = 0; i < block; i++) th[i] = a[i] * b[i];
@@ -360,7 +374,7 @@ void oracle_derv(int n, int ncat, size_t nptn, const double *eval, const double 
     double *v1 = v0 + block, *v2 = v1 + block;
     for (int c = 0; c < ncat; c++)
         for (int i = 0; i < n; i++) {
-            double cof = eval[i] * rates[c];
+            double cof = eval[(size_t)CLS(c) * n + i] * rates[c];
             double val = exp(cof * len) * props[c];
             v0[c * n + i] = val;
             v1[c * n + i] = cof * val;
@@ -402,7 +416,7 @@ double oracle_lnl_from_theta(int n, int ncat, size_t nptn, const double *eval,
     double *val = (double *)malloc(sizeof(double) * block);
     for (int c = 0; c < ncat; c++)
         for (int i = 0; i < n; i++) {
-            double cof = eval[i] * rates[c];
+            double cof = eval[(size_t)CLS(c) * n + i] * rates[c];
             val[c * n + i] = exp(cof * len) * props[c];
         }
     lane4 fin = {{0, 0, 0, 0}};
@@ -455,10 +469,10 @@ double oracle_asc_prob_const_branch(int n, int ncat, size_t n_unobs, const doubl
         double l[4];
         int sc = node_scale[ptn];
         if (dad_states) {
-            const double *t = tip + (size_t)dad_states[ptn] * n;
-            for (int k = 0; k < 4; k++) l[k] = (val[k] * t[k % n]) * b[k];
+            const double *t = tip + (size_t)dad_states[ptn] * n * g_nclass;
+            for (int k = 0; k < 4; k++) l[k] = (val[k] * t[TIPIDX(k)]) * b[k];
             for (size_t i = 4; i < block; i += 4)
-                for (int k = 0; k < 4; k++) l[k] = (val[i + k] * t[(i + k) % n]) * b[i + k] + l[k];
+                for (int k = 0; k < 4; k++) l[k] = (val[i + k] * t[TIPIDX(i + k)]) * b[i + k] + l[k];
         } else {
             const double *a = dad_plh + ptn * block;
             sc += dad_scale[ptn];
@@ -486,7 +500,7 @@ void oracle_asc_theta_sums(int n, int ncat, size_t n_unobs, const double *eval, 
     double *v1 = v0 + block, *v2 = v1 + block;
     for (int c = 0; c < ncat; c++)
         for (int i = 0; i < n; i++) {
-            double cof = eval[i] * rates[c];
+            double cof = eval[(size_t)CLS(c) * n + i] * rates[c];
             double v = exp(cof * len) * props[c];
             v0[c * n + i] = v;
             v1[c * n + i] = cof * v;

@@ -37,6 +37,8 @@ def lib():
     L.oracle_scaling_threshold.restype = C.c_double
     L.oracle_set_threads.argtypes = [C.c_int]
     L.oracle_set_threads.restype = C.c_int
+    L.oracle_set_mixture.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int]
+    L.oracle_set_mixture.restype = None
     L.oracle_log_scaling_threshold.restype = C.c_double
     L.oracle_tip_partial_lh.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp]
     L.oracle_tip_partial_lh.restype = None
@@ -181,9 +183,31 @@ class OracleTree:
         self.inv_evec = np.ascontiguousarray(model.inv_evec, dtype=np.float64)
         self.rates = np.ascontiguousarray(model.rates, dtype=np.float64)
         self.props = np.ascontiguousarray(model.props, dtype=np.float64)
-        self.tip = np.zeros((self.su + 1) * self.n)
-        self.L.oracle_tip_partial_lh(self.n, self.seq_type, self.su, _dp(self.inv_evec), _dp(self.tip))
+        # mixture models: model.cat_class[c] = eigen-system of component c; eval / evec / inv_evec are the
+        # per-class arrays concatenated, tip is [state][class][n] (phylokernelmixture.h:151)
+        self.cat_class = getattr(model, "cat_class", None)
+        self.nclass = int(getattr(model, "nclass", 1))
+        n2 = self.n * self.n
+        if self.nclass > 1:
+            self.cat_class = np.ascontiguousarray(self.cat_class, dtype=np.int32)
+            tip = np.zeros((self.su + 1, self.nclass, self.n))
+            for m in range(self.nclass):
+                t = np.zeros((self.su + 1) * self.n)
+                ie = np.ascontiguousarray(self.inv_evec.reshape(-1)[m * n2:(m + 1) * n2])
+                self.L.oracle_tip_partial_lh(self.n, self.seq_type, self.su, _dp(ie), _dp(t))
+                tip[:, m, :] = t.reshape(self.su + 1, self.n)
+            self.tip = np.ascontiguousarray(tip.reshape(-1))
+        else:
+            self.tip = np.zeros((self.su + 1) * self.n)
+            self.L.oracle_tip_partial_lh(self.n, self.seq_type, self.su, _dp(self.inv_evec), _dp(self.tip))
         self.cache = {}
+
+    def _ctx(self):
+        """select this tree's mixture structure in the C library (a process-wide setting there)"""
+        if self.nclass > 1:
+            self.L.oracle_set_mixture(self.nclass, self.cat_class.ctypes.data_as(C.POINTER(C.c_int)), self.ncat)
+        else:
+            self.L.oracle_set_mixture(1, None, 0)
 
     # ---- tree helpers
     def is_leaf(self, v):
@@ -239,6 +263,7 @@ class OracleTree:
         key = (frm, to)
         if key in self.cache:
             return self.cache[key]
+        self._ctx()
         assert not self.is_leaf(to)
         kids = [(nb, ln) for nb, ln in self.adj[to] if nb != frm]
         assert len(kids) == 2, "oracle handles bifurcating nodes only"
@@ -277,6 +302,7 @@ class OracleTree:
         return None, pa, pb, sfa + sfb, sca, scb
 
     def branch_lnl(self, a, b, length=None):
+        self._ctx()
         ds, dp_, np_, sf, dsc, nsc = self._ends(a, b)
         ln = self.length(a, b) if length is None else length
         plh = np.zeros(self.nptn)
@@ -306,6 +332,7 @@ class OracleTree:
         return self.branch_lnl(leaf, nb)[0], (leaf, nb)
 
     def theta(self, a, b):
+        self._ctx()
         ds, dp_, np_, sf, dsc, nsc = self._ends(a, b)
         th = np.zeros((self.nptn, self.block))
         self.L.oracle_theta(self.n, self.ncat, self.nptn, _dp(self.tip), _u8(ds), _dp(dp_), _dp(np_), _dp(th))
@@ -313,6 +340,7 @@ class OracleTree:
         return th, sf
 
     def derv(self, a, b, length=None, theta=None):
+        self._ctx()
         if theta is None:
             theta, _ = self.theta(a, b)
         ln = self.length(a, b) if length is None else length
@@ -333,6 +361,7 @@ class OracleTree:
         return df, ddf
 
     def lnl_from_theta(self, a, b, length=None, theta=None, sf=None):
+        self._ctx()
         if theta is None:
             theta, sf = self.theta(a, b)
         ln = self.length(a, b) if length is None else length
