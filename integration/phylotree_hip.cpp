@@ -32,8 +32,13 @@ static inline uint64_t hipKey(PhyloNeighbor *nei) { return (uint64_t)(uintptr_t)
 
 bool PhyloTree::hipKernelUsable() {
     if (!aln || !model_factory || !model || !site_rate) return false;
-    if (model->isMixture() || model->isSiteSpecificModel() || !model->isReversible()) return false;
+    if (model->isSiteSpecificModel() || !model->isReversible()) return false;
     int n = aln->num_states;
+    // mixtures (ModelMixture, incl. fused mixture-rate models): 20 states, <= 96 (class, rate) components
+    if (model->isMixture()) {
+        int ncomp = model_factory->fused_mix_rate ? site_rate->getNRate() : site_rate->getNRate() * model->getNMixtures();
+        if (n != 20 || ncomp > 96) return false;
+    }
     return (n == 4 || n == 20 || n == 64) && iqhip_device_count() > 0;
 }
 
@@ -50,7 +55,12 @@ void PhyloTree::setLikelihoodKernelHIP() {
 void PhyloTree::hipSync() {
     size_t norig = aln->size(), nun = model_factory->unobserved_ptns.size();
     size_t nptn = norig + nun;  // phylokernel.h:87: the +ASC constant patterns are appended
-    int ncat = site_rate->getNRate();
+    // the engine's categories are the (class, rate) components of the reference's block:
+    // block = nstates*ncat*nmixture, index (m*ncat + c) (phylokernelmixture.h:55-56); fused
+    // mixture-rate models have one rate per class, block = nstates*ncat (phylokernelmixrate.h:52)
+    const bool mix = model->isMixture(), fused = mix && model_factory->fused_mix_rate;
+    const int nrate = site_rate->getNRate(), nmix = mix ? model->getNMixtures() : 1;
+    int ncat = (mix && !fused) ? nrate * nmix : nrate;
     if (!hip_engine || hip_nptn != nptn || hip_ncat != ncat) {
         if (hip_engine) iqhip_destroy(hip_engine);
         IQHIP_CHECK(iqhip_create(&hip_engine, params->hip_device, aln->num_states, ncat, nptn, leafNum));
@@ -61,10 +71,26 @@ void PhyloTree::hipSync() {
     if (!tip_partial_lh_computed) {
         computeTipPartialLikelihood();  // also fills ptn_freq, ptn_invar (phylotreesse.cpp:359-371)
         vector<double> rates(ncat), props(ncat);
-        for (int c = 0; c < ncat; c++) { rates[c] = site_rate->getRate(c); props[c] = site_rate->getProp(c); }
-        IQHIP_CHECK(iqhip_set_model(hip_engine, model->getEigenvalues(), model->getEigenvectors(),
-                                    model->getInverseEigenvectors(), &rates[0], &props[0],
-                                    aln->STATE_UNKNOWN, tip_partial_lh));
+        if (!mix) {
+            for (int c = 0; c < ncat; c++) { rates[c] = site_rate->getRate(c); props[c] = site_rate->getProp(c); }
+            IQHIP_CHECK(iqhip_set_model(hip_engine, model->getEigenvalues(), model->getEigenvectors(),
+                                        model->getInverseEigenvectors(), &rates[0], &props[0],
+                                        aln->STATE_UNKNOWN, tip_partial_lh));
+        } else {
+            // component weights as the reference folds them into `val` (phylokernelmixture.h:762-771:
+            // getProp(c) * ModelMixture::prop[m]; fused: getProp(c), phylokernelmixrate.h:739);
+            // eigen-systems and tip_partial_lh[state][class][i] are already concatenated per class
+            vector<int32_t> cls(ncat);
+            for (int q = 0; q < ncat; q++) {
+                const int m = fused ? q : q / nrate, c = fused ? q : q % nrate;
+                cls[q] = m;
+                rates[q] = site_rate->getRate(c);
+                props[q] = fused ? site_rate->getProp(c) : site_rate->getProp(c) * ((ModelMixture *)model)->prop[m];
+            }
+            IQHIP_CHECK(iqhip_set_mixture_model(hip_engine, nmix, &cls[0], model->getEigenvalues(),
+                                                model->getEigenvectors(), model->getInverseEigenvectors(),
+                                                &rates[0], &props[0], aln->STATE_UNKNOWN, tip_partial_lh));
+        }
         if (!hip_aln_pushed) {
             vector<uint8_t> states((size_t)leafNum * nptn);
             for (size_t ptn = 0; ptn < nptn; ptn++)

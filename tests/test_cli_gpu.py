@@ -108,3 +108,32 @@ def test_cli_errors(tmp_path):
     assert r.returncode == 2 and "cannot open alignment file" in r.stderr
     r = subprocess.run([BIN, "-s", EXAMPLE], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr
+
+
+def test_reference_protein_alignment(pkg, synth, oracle, tmp_path):
+    """prot_M126_27_269.phy (the protein data file of the reference's test scripts, test_scripts/test_configs.txt):
+    27 sequences x 269 amino acids with gaps and X; Poisson+G4 through the stand-alone driver, and a profile
+    mixture through the library, both against the oracle."""
+    prot = os.path.join(HERE, "golden", "prot_M126_27_269.phy")
+    aln = pkg.Alignment(prot)
+    assert (aln.nseq, aln.nsite, aln.nstates, aln.seq_type) == (27, 269, 20, pkg.SEQ_PROTEIN)
+    st, fr, sp, _ = aln.arrays()
+    assert fr.sum() == 269 and st.max() == 23
+    nwk = synth.random_tree_newick(27, 3)
+    tf = tmp_path / "p.nwk"
+    tf.write_text(named_tree(nwk, aln.seq_names) + "\n")
+    pre = str(tmp_path / "prot")
+    run_cli(["-s", prot, "-te", str(tf), "-m", "POISSON+G4{0.8}", "-blfix", "-wsl", "-pre", pre])
+    model = aln.build_model("POISSON+G4{0.8}")
+    ot = oracle.OracleTree(nwk, 20, 1, st, fr, None, model)
+    ref, _ = ot.likelihood()
+    assert abs(float(read_report(pre)["lnL"]) - ref) <= 1e-9 * abs(ref)
+    mix = synth.mixture_model(20, 3, 77, ncat=4)
+    t = pkg.PhyloTree(nwk)
+    t.set_alignment(20, 1, st, fr)
+    t.set_model(mix)
+    t.attach_engine(0)
+    om = oracle.OracleTree(nwk, 20, 1, st, fr, None, mix)
+    refm, _ = om.likelihood()
+    assert abs(t.compute_likelihood() - refm) <= 1e-9 * abs(refm)
+    assert refm > ref - 5000        # sanity: same data, both finite and of the same order

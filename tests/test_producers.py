@@ -267,3 +267,13 @@ def test_sitelh_writer(pkg, tmp_path):
     lines = out.read_text().splitlines()
     assert lines[0] == "1 12" and lines[1].startswith("Site_Lh   ")
     assert np.allclose([float(x) for x in lines[1].split()[1:]], lh[sp])
+
+
+def test_reference_protein_file(pkg):
+    aln = pkg.Alignment(os.path.join(HERE, "golden", "prot_M126_27_269.phy"))
+    assert (aln.nseq, aln.nsite, aln.nstates, aln.state_unknown) == (27, 269, 20, 23)
+    st, fr, sp, cc = aln.arrays()
+    assert aln.npattern == len(set(map(bytes, st[:, sp].T))) and fr.sum() == 269
+    assert aln.seq_names[0] == "Acrasis_rosea"
+    f = aln.state_freq()
+    assert abs(f.sum() - 1) < 1e-12 and f.min() >= 1e-4
