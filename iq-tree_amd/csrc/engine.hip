@@ -130,6 +130,13 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
             return fail(IQHIP_ERR_NOMEM, "iqhip_create: device allocation failed");
         }
     }
+    // 4-state kernel, two lanes per pattern: twice the waves with half the register state each, as long as
+    // they all fit the chip at once (2 waves per SIMD).  Measured, GTR+G4 50 taxa: 10k..65k patterns 0.116..
+    // 0.130 ms -> 0.086..0.114 ms; 80k patterns 0.145 -> 0.191 ms (second round).  IQHIP_LANE_SPLIT=1|2 overrides
+    if (!e->mfma && ncat % 2 == 0) {
+        e->lane_split = (2 * (e->nptn_pad / 64) <= 2 * (int64_t)e->num_cus * 4) ? 2 : 1;
+        if (const char *ls = getenv("IQHIP_LANE_SPLIT")) e->lane_split = (atoi(ls) == 2) ? 2 : 1;
+    }
     e->d_result = e->d_result_own;
     hipMemsetAsync(e->d_theta, 0, P * e->block * sizeof(double), e->stream);
     hipMemsetAsync(e->d_pattern_lh, 0, P * sizeof(double), e->stream);
@@ -442,7 +449,7 @@ static int ensure_plan_capacity(iqhip_engine *e, int nops) {
 }
 
 static int ensure_slab_rows(iqhip_engine *e, int nrows) {
-    const int64_t need = (int64_t)nrows * e->ntiles;
+    const int64_t need = (int64_t)nrows * e->ntiles * e->lane_split;
     if (need <= e->slab_cap) return IQHIP_OK;
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->d_slab) hipFree(e->d_slab);
@@ -523,6 +530,10 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
             target = 0;
             if (e->mfma && e->ntiles < 6 * simds && nops >= 12)
                 target = (int)std::min<int64_t>(nops / 2, std::max<int64_t>(3, ((int64_t)nops * e->ntiles + 4 * simds - 1) / (4 * simds)));
+            // 4-state kernel: only while the whole alignment is at most one wave per SIMD, where a traversal
+            // is a latency-bound chain (50 taxa GTR+G4: 5k patterns 0.082 -> 0.045 ms, 20k 0.086 -> 0.060 ms;
+            // 60k patterns 0.109 -> 0.126 ms, so not there)
+            if (!e->mfma && e->ntiles * e->lane_split <= simds && nops >= 12) target = std::max(6, nops / 4);
         }
         if (target > 0 && target < nops && nops >= 4) {
             std::unordered_map<uint64_t, int> prod;
@@ -802,7 +813,7 @@ static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, 
     }
     rc = ensure_slab_rows(e, 2 + nops);
     if (rc) return rc;
-    const int nwaves = (int)e->ntiles;
+    const int nwaves = (int)e->ntiles * e->lane_split;  // columns of the wave-partial slab
     timing_begin(e);
     const int *table = reinterpret_cast<const int *>(e->d_ops + e->plan_table_off);
     if (e->plan_nunits > 0) {  // stage 1: the independent subtrees, one set of workgroups each

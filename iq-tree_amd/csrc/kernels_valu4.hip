@@ -104,11 +104,11 @@ struct Trav4Args {
 
 // a[x] (x = 0..3) of a LEAF child for category c: table row (fast path) or E*tip evaluated on
 // the fly when some lane of the wave holds an IUPAC ambiguity code (slow, wave-uniform)
-template <int C>
+template <int CF>
 __device__ __forceinline__ void leaf_cat4(const double *reg /* [ex B][table 5B] */, const double *s_tip,
                                           const CONST_AS double *U, int s, int row, bool slow,
                                           int state_unknown, int c, double (&a)[4]) {
-    constexpr int B = 4 * C;
+    constexpr int B = 4 * CF;
     if (__builtin_expect(slow, 0)) {
         double l[4];
 #pragma unroll
@@ -137,12 +137,13 @@ __device__ __forceinline__ void leaf_cat4(const double *reg /* [ex B][table 5B] 
 // by category; right after category c has been read the same registers are re-targeted at
 // op k+1's streamed child (nx_pf), so the prefetch needs no second register set and no copy.
 // Returns lh_max (0 for LEAF-LEAF, which the reference never rescales).
-template <int C>
+// With SP = 2 lanes per pattern a lane owns C = CF/2 of the block's CF categories, starting at `coff`.
+template <int C, int CF>
 __device__ __forceinline__ double node_update4(bool leafL, bool holdL, bool leafR, const double *regL,
                                                const double *regR, const double *s_tip,
                                                const CONST_AS double *U, const CONST_AS double *uinv,
                                                int sL, int sR, int state_unknown, const char *nx_pf,
-                                               char *dst, double (&PF)[4 * C], const double (&HOLD)[4 * C],
+                                               char *dst, int coff, double (&PF)[4 * C], const double (&HOLD)[4 * C],
                                                double (&prev)[4 * C]) {
     bool slowL = false, slowR = false;
     int rowL = 0, rowR = 0;
@@ -159,15 +160,15 @@ __device__ __forceinline__ double node_update4(bool leafL, bool holdL, bool leaf
     for (int c = 0; c < C; c++) {
         double a[4], b[4], tmp[4];
         if (leafL) {
-            leaf_cat4<C>(regL, s_tip, U, sL, rowL, slowL, state_unknown, c, a);
+            leaf_cat4<CF>(regL, s_tip, U, sL, rowL, slowL, state_unknown, coff + c, a);
         } else {
             double l[4];
             if (holdL) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) l[i] = regL[c * 4 + i] * HOLD[c * 4 + i];
+                for (int i = 0; i < 4; i++) l[i] = regL[(coff + c) * 4 + i] * HOLD[c * 4 + i];
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; i++) l[i] = regL[c * 4 + i] * PF[c * 4 + i];
+                for (int i = 0; i < 4; i++) l[i] = regL[(coff + c) * 4 + i] * PF[c * 4 + i];
             }
 #pragma unroll
             for (int x = 0; x < 4; x++) {
@@ -184,11 +185,11 @@ __device__ __forceinline__ double node_update4(bool leafL, bool holdL, bool leaf
             PF[c * 4] = t0.x; PF[c * 4 + 1] = t0.y; PF[c * 4 + 2] = t1.x; PF[c * 4 + 3] = t1.y;
         }
         if (leafR) {
-            leaf_cat4<C>(regR, s_tip, U, sR, rowR, slowR, state_unknown, c, b);
+            leaf_cat4<CF>(regR, s_tip, U, sR, rowR, slowR, state_unknown, coff + c, b);
         } else {
             double r[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) r[i] = regR[c * 4 + i] * prev[c * 4 + i];
+            for (int i = 0; i < 4; i++) r[i] = regR[(coff + c) * 4 + i] * prev[c * 4 + i];
 #pragma unroll
             for (int x = 0; x < 4; x++) {
                 double v = U[x * 4] * r[0];
@@ -243,10 +244,16 @@ __device__ __forceinline__ void store_vec4_off(double *base, uint32_t voff, cons
 // is read synchronously); the fast instantiation has no such path, so that the VMEM sequence
 // of a loop iteration is the same on every path and the compiler can use counted vmcnt waits
 // (stores of op k-1 stay in flight while op k computes).
-template <int C, int WG, bool HAS_LOAD>
+// SP = 2: two lanes per pattern -- a wave covers half a tile (32 patterns) and each lane half of the
+// categories, so a small alignment yields twice as many waves with half the register state each (the
+// 4-state kernel is latency / occupancy limited below ~4 waves per SIMD).  The memory layout is
+// unchanged: the lane's categories are rows [2*coff, 2*coff + 2*CL) of the tile.
+template <int C, int WG, bool HAS_LOAD, int SP>
 __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
+    static_assert(SP == 1 || (SP == 2 && C % 2 == 0), "SP = 2 needs an even category count");
     constexpr int B = 4 * C;
-    constexpr int WPB = WG / 64;  // waves (= 64-pattern tiles) per block
+    constexpr int CL = C / SP, BL = 4 * CL;  // categories / doubles per lane
+    constexpr int WPB = WG / 64;  // waves per block (64 patterns each, 32 with SP = 2)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *s_tip = smem;             // [32][4]
     double *s_val = smem + 128;       // [B]
@@ -264,12 +271,19 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // make it provably uniform
     const int seg = (int)blockIdx.x / A.ngroups;  // scalar
     const int k_begin = as_const(A.segs)[2 * seg], k_end = k_begin + as_const(A.segs)[2 * seg + 1];
-    const int64_t tile = (int64_t)((int)blockIdx.x - seg * A.ngroups) * WPB + wave;
-    const bool active = tile < A.ntiles;
-    const int64_t tl = active ? tile : 0;
-    const int gw = (int)tl;               // global wave id == tile id
-    const int64_t ptn = tl * 64 + lane;
-    const uint32_t voff = (uint32_t)(tl * (64 * B * 8) + lane * 16);  // bytes into a vector slab
+    // wave -> (tile, 32-pattern half); lane -> (pattern, category half)
+    const int64_t wtile = (int64_t)((int)blockIdx.x - seg * A.ngroups) * WPB + wave;
+    const bool active = wtile < A.ntiles * SP;
+    const int64_t wt = active ? wtile : 0;
+    const int gw = (int)wt;               // global wave id
+    const int64_t tl = wt / SP;           // 64-pattern tile of the vector layout
+    const int pl = (SP == 1) ? lane : (int)(wt & 1) * 32 + (lane & 31);  // pattern within the tile
+    const int hl = (SP == 1) ? 0 : (lane >> 5);                           // category half of this lane
+    const int coff = hl * CL;
+    const bool lead = (hl == 0);          // the lane that owns the pattern's scalars
+    const int64_t ptn = tl * 64 + pl;
+    const uint32_t voff = (uint32_t)(tl * (64 * B * 8) + pl * 16 + coff * 2048);  // bytes into a vector slab
+    const uint32_t doff = (uint32_t)(lane * 16);                      // ... into the dummy window
     const uint32_t soff = (uint32_t)(ptn * 2);                        // bytes into a scale array
     const uint32_t poff = (uint32_t)ptn;                              // bytes into a state row
 
@@ -280,18 +294,18 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
     const CONST_AS double *uinv = as_const(A.inv_evec);
     const CONST_AS DevOp *ops = as_const(A.ops);
 
-    double prev[B], PF[B], HOLD[B];
+    double prev[BL], PF[BL], HOLD[BL];
     int hold_sc = 0;
     int pf_sc = 0, prev_sc = 0;
 #pragma unroll
-    for (int e = 0; e < B; e++) { prev[e] = 0.0; PF[e] = 0.0; HOLD[e] = 0.0; }
+    for (int e = 0; e < BL; e++) { prev[e] = 0.0; PF[e] = 0.0; HOLD[e] = 0.0; }
 
     // everything op k needs from memory is requested while op k-1 computes.  Prime for op 0.
     // (ops[nops] is a sentinel whose pointers are valid dummies, so the requests are unconditional)
     if (active) {
         const CONST_AS DevOp *nx = ops + k_begin;
         const int nreal = nx->real_mask;
-        load_vec4_off<C>(nx->pf, (nreal & 1) ? voff : (uint32_t)(lane * 16), PF);
+        load_vec4_off<CL>(nx->pf, (nreal & 1) ? voff : doff, PF);
         pf_sc = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(nx->pf_sc) +
                                                    ((nreal & 1) ? soff : (uint32_t)(lane * 2)));
     }
@@ -353,7 +367,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
             if (HAS_LOAD && op->right_kind == CHILD_LOAD) {
                 // both children come from memory: the left one was streamed into PF; the right
                 // one is read now into `prev`, which is dead here (it is not an input of this op)
-                load_vec4_off<C>(op->ld, voff, prev);
+                load_vec4_off<CL>(op->ld, voff, prev);
                 prev_sc = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(op->ld_sc) + soff);
             }
             if (!leafR) sc += prev_sc;
@@ -364,12 +378,13 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
             // small cache-resident window of the dummy buffers: no memory traffic.
             const CONST_AS DevOp *nx = ops + (k + 1);
             const int nreal = nx->real_mask;
-            const char *nx_pf = reinterpret_cast<const char *>(nx->pf) + ((nreal & 1) ? voff : (uint32_t)(lane * 16));
+            const char *nx_pf = reinterpret_cast<const char *>(nx->pf) + ((nreal & 1) ? voff : doff);
             pf_sc = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(nx->pf_sc) +
                                                        ((nreal & 1) ? soff : (uint32_t)(lane * 2)));
             char *dstp = reinterpret_cast<char *>(op->dst) + voff;
-            const double lh_max = node_update4<C>(leafL, holdL, leafR, s_reg + op->lds_left, s_reg + op->lds_right,
-                                                  s_tip, U, uinv, sL, sR, A.state_unknown, nx_pf, dstp, PF, HOLD, prev);
+            double lh_max = node_update4<CL, C>(leafL, holdL, leafR, s_reg + op->lds_left, s_reg + op->lds_right,
+                                                s_tip, U, uinv, sL, sR, A.state_unknown, nx_pf, dstp, coff, PF, HOLD, prev);
+            if (SP == 2) lh_max = fmax(lh_max, __shfl_xor(lh_max, 32, 64));  // both category halves of the pattern
             // ---- scaling (SIMD rule, phylokernel.h:379-392,461-474); TIP-TIP never scales
             const bool do_scale = !(leafL && leafR) && (lh_max < kScalingThreshold) && (invar == 0.0);
             double my_scale = 0.0;
@@ -377,11 +392,11 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
             if (__builtin_expect(any != 0, 0)) {  // rare, wave-uniform
                 if (do_scale) {
 #pragma unroll
-                    for (int e = 0; e < B; e++) prev[e] *= kScalingThresholdInv;
+                    for (int e = 0; e < BL; e++) prev[e] *= kScalingThresholdInv;
                     sc += 1;
-                    my_scale = (ptn < A.nptn) ? kLogScalingThreshold * freq : 0.0;
+                    my_scale = (lead && ptn < A.nptn) ? kLogScalingThreshold * freq : 0.0;
 #ifndef IQHIP_ABLATE_NOSTORE
-                    store_vec4_off<C>(op->dst, voff, prev);
+                    store_vec4_off<CL>(op->dst, voff, prev);
 #endif
                 }
             }
@@ -390,11 +405,11 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
                 // this result is the left child of a join a few ops ahead whose other subtree is a
                 // plain chain: park it in registers instead of re-reading 8 KiB per wave from memory
 #pragma unroll
-                for (int e = 0; e < B; e++) HOLD[e] = prev[e];
+                for (int e = 0; e < BL; e++) HOLD[e] = prev[e];
                 hold_sc = sc;
             }
 #ifndef IQHIP_ABLATE_NOSTORE
-            *reinterpret_cast<int16_t *>(reinterpret_cast<char *>(op->dst_sc) + soff) = (int16_t)sc;
+            if (SP == 1 || lead) *reinterpret_cast<int16_t *>(reinterpret_cast<char *>(op->dst_sc) + soff) = (int16_t)sc;
 #endif
             // deterministic reduction: wave partial -> slab[2+k][gw]
             double ws = 0.0;
@@ -407,35 +422,37 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
 
     if (A.has_root) {
         // ---- branch lnL, phylokernel.h:806-838 (leaf form) / :930-956 (internal form)
-        double Bv[B];
+        double Bv[BL];
+        const double *sv = s_val + coff * 4;  // this lane's categories
         if (A.root.b_kind == CHILD_PREV) {
 #pragma unroll
-            for (int e = 0; e < B; e++) Bv[e] = prev[e];
+            for (int e = 0; e < BL; e++) Bv[e] = prev[e];
         } else {
-            load_vec4<C>(A.root.b, tl, lane, Bv);
+            load_vec4_off<CL>(A.root.b, voff, Bv);
         }
         double lh = 0.0;
         if (A.root.a_kind == CHILD_LEAF) {
             const int s = A.root.a_states[ptn];
 #pragma unroll
-            for (int e = 0; e < B; e++) lh = fma(s_val[e] * s_tip[s * 4 + (e & 3)], Bv[e], lh);
+            for (int e = 0; e < BL; e++) lh = fma(sv[e] * s_tip[s * 4 + (e & 3)], Bv[e], lh);
         } else {
-            double Av[B];
+            double Av[BL];
             if (A.root.a_kind == CHILD_PREV) {
 #pragma unroll
-                for (int e = 0; e < B; e++) Av[e] = prev[e];
+                for (int e = 0; e < BL; e++) Av[e] = prev[e];
             } else {
-                load_vec4<C>(A.root.a, tl, lane, Av);
+                load_vec4_off<CL>(A.root.a, voff, Av);
             }
 #pragma unroll
-            for (int e = 0; e < B; e++) lh = fma(s_val[e] * Av[e], Bv[e], lh);
+            for (int e = 0; e < BL; e++) lh = fma(sv[e] * Av[e], Bv[e], lh);
         }
+        if (SP == 2) lh += __shfl_xor(lh, 32, 64);  // sum over both category halves
         double pc = 0.0;
         if (A.nobs < A.nptn) {
             // +ASC: prob_const = sum over the unobserved constant patterns of lh_ptn, the block sum
             // multiplied by 2^-256 once when the summed scale counters are >= 1 (phylokernel.h:894-897,
             // :989-992), then + ptn_invar
-            if (ptn >= A.nobs && ptn < A.nptn) {
+            if (lead && ptn >= A.nobs && ptn < A.nptn) {
                 int ssc = (A.root.b_kind == CHILD_PREV) ? prev_sc : (int)A.root.b_sc[ptn];
                 if (A.root.a_kind != CHILD_LEAF) ssc += (A.root.a_kind == CHILD_PREV) ? prev_sc : (int)A.root.a_sc[ptn];
                 pc = (ssc >= 1 ? lh * kScalingThreshold : lh) + invar;
@@ -443,8 +460,8 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
         }
         lh += invar;
         const double plh = log(fabs(lh));
-        A.pattern_lh[ptn] = plh;
-        const double acc = (ptn < A.nobs) ? plh * freq : 0.0;
+        if (SP == 1 || lead) A.pattern_lh[ptn] = plh;
+        const double acc = (lead && ptn < A.nobs) ? plh * freq : 0.0;
         const double ws = wave_sum(acc);
         const double wpc = (A.nobs < A.nptn) ? wave_sum(pc) : 0.0;
         if (lane == 0) {
@@ -454,26 +471,30 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
     }
 }
 
-template <int C, int WG, bool HAS_LOAD>
+template <int C, int WG, bool HAS_LOAD, int SP>
 static hipError_t launch_trav_l(iqhip_engine *e, Trav4Args &A) {
     constexpr int B = 4 * C;
     const size_t lds = (size_t)(128 + B + (size_t)e->plan_lds_doubles) * sizeof(double) +
                        (size_t)e->plan_state_slots * WG;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse4<C, WG, HAS_LOAD>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse4<C, WG, HAS_LOAD, SP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     constexpr int WPB = WG / 64;
-    A.ngroups = (int)((e->ntiles + WPB - 1) / WPB);
-    hipLaunchKernelGGL((k_traverse4<C, WG, HAS_LOAD>), dim3((unsigned)(A.ngroups * A.nsegs_launch)), dim3(WG), lds, e->stream, A);
+    A.ngroups = (int)((e->ntiles * SP + WPB - 1) / WPB);
+    hipLaunchKernelGGL((k_traverse4<C, WG, HAS_LOAD, SP>), dim3((unsigned)(A.ngroups * A.nsegs_launch)), dim3(WG), lds, e->stream, A);
     return hipGetLastError();
 }
 
 template <int C, int WG>
 static hipError_t launch_trav_c(iqhip_engine *e, Trav4Args &A) {
-    return A.has_load ? launch_trav_l<C, WG, true>(e, A) : launch_trav_l<C, WG, false>(e, A);
+    if constexpr (C % 2 == 0) {
+        if (e->lane_split == 2)
+            return A.has_load ? launch_trav_l<C, WG, true, 2>(e, A) : launch_trav_l<C, WG, false, 2>(e, A);
+    }
+    return A.has_load ? launch_trav_l<C, WG, true, 1>(e, A) : launch_trav_l<C, WG, false, 1>(e, A);
 }
 
 template <int C>

@@ -700,3 +700,26 @@ def test_staged_plan_is_refused_for_reused_buffers(pkg, synth, oracle, monkeypat
         nb = t.neighbors(leaf)[0][0]
         v = t.compute_likelihood_branch(leaf, nb)      # re-roots: steals buffers of the old orientation
         assert abs(v - ref) <= LNL_RTOL * abs(ref)
+
+
+@pytest.mark.parametrize("ncat,ntaxa,kw", [(4, 30, dict(missing=0.05)), (2, 40, dict(lo=0.3, hi=0.8, caterpillar=True)),
+                                           (6, 12, dict(pinvar=0.2)), (8, 9, {})])
+def test_lane_split_gives_identical_vectors(pkg, synth, oracle, ncat, ntaxa, kw, monkeypatch):
+    """4-state kernel with two lanes per pattern (each lane half of the categories) against one lane per
+    pattern: same vectors and counters bit for bit; the root lnL sums the two halves in another order."""
+    out = []
+    for ls in ("1", "2"):
+        monkeypatch.setenv("IQHIP_LANE_SPLIT", ls)
+        t, ot, *_ = make_case(synth, oracle, pkg, ntaxa, 500, 4, ncat, 9100 + ncat + ntaxa, **kw)
+        lnl = t.compute_likelihood()
+        a, b = t.current_branch()
+        out.append((lnl, t.fetch_partial(a, b), t.fetch_scale_num(a, b), t.neighbor_info(a, b)["lh_scale_factor"],
+                    t.compute_pattern_likelihood(), t.compute_likelihood_derv(a, b)))
+        ref, _ = ot.likelihood()
+        assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+        assert check_all_vectors(t, ot) == ntaxa - 2
+    x, y = out
+    assert abs(x[0] - y[0]) <= 1e-13 * abs(x[0])
+    assert np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]) and x[3] == y[3]
+    np.testing.assert_allclose(x[4], y[4], rtol=1e-13)
+    assert x[5] == y[5]                     # theta / derivative kernels are not affected by the traversal mapping
