@@ -23,11 +23,21 @@ CASES = [
     dict(name="protein_deep_scaled", n=20, ncat=4, seq_type=1, ntaxa=140, nsites=60, seed=15, missing=0.0,
          pinvar=0.0, lo=0.3, hi=0.7, caterpillar=True),
     dict(name="codon64", n=64, ncat=1, seq_type=2, ntaxa=9, nsites=200, seed=16, missing=0.02, pinvar=0.0),
+    # mixtures: ncat = number of (class, rate) components
+    dict(name="protein_mix3_g4", n=20, ncat=12, seq_type=1, ntaxa=11, nsites=250, seed=17, missing=0.03, pinvar=0.0,
+         mixture=dict(nclass=3, ncat=4, fused=False)),
+    dict(name="protein_mix4_fused_deep", n=20, ncat=4, seq_type=1, ntaxa=120, nsites=60, seed=18, missing=0.0,
+         pinvar=0.0, lo=0.3, hi=0.7, caterpillar=True, mixture=dict(nclass=4, ncat=1, fused=True)),
 ]
 
 
 def build_case(c, synth, od):
-    if c["n"] == 4:
+    sim = None
+    if c.get("mixture"):
+        mx = c["mixture"]
+        model = synth.mixture_model(c["n"], mx["nclass"], c["seed"], ncat=mx["ncat"], fused=mx["fused"])
+        sim = model.classes[0]
+    elif c["n"] == 4:
         model = synth.gtr_model(alpha=0.9, ncat=c["ncat"], pinvar=c["pinvar"])
     else:
         model = synth.random_reversible_model(c["n"], c["seed"], alpha=0.9 if c["ncat"] > 1 else None,
@@ -35,7 +45,7 @@ def build_case(c, synth, od):
     su = od.state_unknown_for(c["n"], c["seq_type"])
     nwk = synth.random_tree_newick(c["ntaxa"], c["seed"], c.get("lo", 0.02), c.get("hi", 0.2),
                                    c.get("caterpillar", False))
-    st = synth.simulate_alignment(nwk, model, c["nsites"], c["seed"] + 1, c["missing"], su)
+    st = synth.simulate_alignment(nwk, sim or model, c["nsites"], c["seed"] + 1, c["missing"], su)
     pat, freq = synth.compress_patterns(st)
     invar = synth.ptn_invar_for(pat, model)
     return model, nwk, pat, freq, invar
