@@ -203,6 +203,11 @@ int iqhip_fetch_theta(iqhip_engine *e, double *out /* nptn*block, ref layout */)
  *   rell[s] = dotProduct(pattern_lh, boot_samples[s]) (phylokernel.h:55-61), accumulated in double.
  *   The _async form leaves the scores in the result vector [0, nsamples) for a sharded caller to
  *   all-reduce before iqhip_result_read. */
+/* _pattern_lh_cat of the reference's scalar kernels (phylotreesse.cpp:1190-1237; consumer
+ * RateGamma::computePatternRates, model/rategamma.cpp:241-262): per pattern and category
+ * sum_i exp(eval_i r_c len) prop_c theta[ptn][c][i] for the branch of the last iqhip_compute_theta,
+ * unscaled, out[ptn*ncat + c]. */
+int iqhip_pattern_lh_cat(iqhip_engine *e, double len, double *out /* nptn*ncat */);
 int iqhip_fetch_pattern_lh_scaled(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b, double *out /* nptn */);
 int iqhip_set_boot_samples(iqhip_engine *e, const float *samples, int nsamples);
 int iqhip_rell(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b, double *rell /* nsamples */);

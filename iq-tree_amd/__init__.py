@@ -30,7 +30,7 @@ IQHIP_SYMBOLS = [
     "iqhip_synchronize", "iqhip_fetch_scale_num", "iqhip_fetch_pattern_lh", "iqhip_fetch_partial",
     "iqhip_fetch_theta", "iqhip_upload_partial", "iqhip_timing_enable", "iqhip_timing_read",
     "iqhip_fetch_pattern_lh_scaled", "iqhip_set_boot_samples", "iqhip_rell", "iqhip_rell_async",
-    "iqhip_set_mixture_model",
+    "iqhip_set_mixture_model", "iqhip_pattern_lh_cat",
 ]
 
 
@@ -179,6 +179,7 @@ def libiqhost():
     lib.iqhost_fetch_partial.argtypes = [vp, C.c_int, C.c_int, dp]
     lib.iqhost_fetch_pattern_lh.argtypes = [vp, dp]
     lib.iqhost_compute_pattern_likelihood.argtypes = [vp, dp]
+    lib.iqhost_compute_pattern_lh_cat.argtypes = [vp, dp]
     lib.iqhost_set_boot_samples.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     lib.iqhost_compute_rell.argtypes = [vp, dp, C.c_int]
     lib.iqhost_last_plan.argtypes = [vp, C.POINTER(C.c_int), dp, C.POINTER(C.c_uint64), C.c_int]
@@ -456,6 +457,12 @@ class PhyloTree:
         """PhyloTree::computePatternLikelihood: per-pattern lnL with the scaling events put back."""
         out = np.zeros(self.nptn)
         self._chk(self.lib.iqhost_compute_pattern_likelihood(self.h, _dptr(out)))
+        return out
+
+    def compute_pattern_lh_cat(self):
+        """_pattern_lh_cat[nptn, ncat] of the current branch (unscaled category likelihoods)."""
+        out = np.zeros((self.nptn, self.ncat))
+        self._chk(self.lib.iqhost_compute_pattern_lh_cat(self.h, _dptr(out)))
         return out
 
     def set_boot_samples(self, samples):

@@ -2,6 +2,7 @@
 // extern "C" entry points declared in include/iqhip.h.  There is NO CPU fallback in this
 // library: every compute entry point launches HIP kernels or fails with a status.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -601,6 +602,11 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
             }
         }
     }
+    if (getenv("IQHIP_DEBUG_PLAN")) {
+        fprintf(stderr, "[iqhip] plan: %d ops, %zu units (", nops, units.size());
+        for (auto &u : units) fprintf(stderr, "%d ", u.second);
+        fprintf(stderr, ") top %d ops\n", nops - top_begin);
+    }
     const int table_ints = 2 * (1 + (int)units.size());
     const int table_ops = (int)((table_ints * sizeof(int) + sizeof(DevOp) - 1) / sizeof(DevOp));
     rc = ensure_plan_capacity(e, nops + kSentinels + table_ops);
@@ -1161,6 +1167,22 @@ extern "C" int iqhip_fetch_pattern_lh_scaled(iqhip_engine *e, iqhip_branch_end a
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(out, e->d_ptn_scaled, sizeof(double) * (size_t)e->nptn, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_pattern_lh_cat(iqhip_engine *e, double len, double *out) {
+    if (!e || !out) return fail(IQHIP_ERR_INVALID, "null argument");
+    if (!e->theta_valid) return fail(IQHIP_ERR_INVALID, "iqhip_pattern_lh_cat needs iqhip_compute_theta first");
+    if (!(len >= 0.0)) return fail(IQHIP_ERR_INVALID, "negative or NaN branch length");
+    HIPCHK(hipSetDevice(e->device));
+    const size_t count = (size_t)e->nptn * e->ncat;
+    double *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_out, sizeof(double) * count));
+    hipError_t s = launch_pattern_lh_cat(e, len, d_out);
+    if (s == hipSuccess) s = hipMemcpyAsync(out, d_out, sizeof(double) * count, hipMemcpyDeviceToHost, e->stream);
+    if (s == hipSuccess) s = hipStreamSynchronize(e->stream);
+    hipFree(d_out);
+    if (s != hipSuccess) return fail(IQHIP_ERR_HIP, hipGetErrorString(s));
     return IQHIP_OK;
 }
 

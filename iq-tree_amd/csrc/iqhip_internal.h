@@ -185,6 +185,7 @@ hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, d
 // kernels_rell.hip
 hipError_t launch_pattern_lh_scaled(iqhip_engine *e, const int16_t *sc_a, const int16_t *sc_b, double *out);
 hipError_t launch_rell(iqhip_engine *e, double *out);
+hipError_t launch_pattern_lh_cat(iqhip_engine *e, double len, double *out);
 
 // kernels_mfma.hip (nstates 20 / 64)
 hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs, int nwaves);

@@ -55,6 +55,43 @@ __global__ __launch_bounds__(256) void k_rell(const double *__restrict__ ptn_lh,
     if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 
+// _pattern_lh_cat of the scalar kernels (phylotreesse.cpp:1190-1237): per pattern and category
+// sum_i exp(eval_i r_c t) prop_c theta[ptn][c][i], from the theta buffer of the current branch, unscaled.
+// Generic in the vector layout: 64-pattern tiles (4 states) or 16-pattern tiles (20 / 64 states).
+__global__ __launch_bounds__(256) void k_pattern_lh_cat(const double *__restrict__ theta, const double *__restrict__ evalc,
+                                                        const double *__restrict__ rates, const double *__restrict__ props,
+                                                        double len, int n, int ncat, int tile, int64_t nptn,
+                                                        double *__restrict__ out) {
+    extern __shared__ double s_val[];  // [ncat][n]
+    const int B = n * ncat;
+    for (int t = threadIdx.x; t < B; t += 256) {
+        const int c = t / n;
+        s_val[t] = exp(evalc[t] * rates[c] * len) * props[c];
+    }
+    __syncthreads();
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nptn * ncat) return;
+    const int64_t p = idx / ncat;
+    const int c = (int)(idx - p * ncat);
+    const int64_t tl = p / tile;
+    const int pl = (int)(p - tl * tile);
+    const double *base = theta + (size_t)tl * tile * B;
+    double acc = 0.0;
+    for (int i = 0; i < n; i++) {
+        const int e = c * n + i;
+        const double th = (tile == 64) ? base[(size_t)(e >> 1) * 128 + pl * 2 + (e & 1)] : base[(size_t)e * 16 + pl];
+        acc += s_val[e] * th;
+    }
+    out[idx] = acc;
+}
+
+hipError_t launch_pattern_lh_cat(iqhip_engine *e, double len, double *out) {
+    const int64_t total = e->nptn * e->ncat;
+    hipLaunchKernelGGL(k_pattern_lh_cat, dim3((unsigned)((total + 255) / 256)), dim3(256), sizeof(double) * e->block, e->stream,
+                       e->d_theta, e->d_evalc, e->d_rates, e->d_props, len, e->n, e->ncat, e->tile, e->nptn, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_pattern_lh_scaled(iqhip_engine *e, const int16_t *sc_a, const int16_t *sc_b, double *out) {
     const int64_t P = e->nptn_pad;
     hipLaunchKernelGGL(k_pattern_lh_scaled, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, e->stream, e->d_pattern_lh,

@@ -219,6 +219,7 @@ int iqhost_fetch_partial(void *h, int from, int to, double *out) {
 }
 int iqhost_fetch_pattern_lh(void *h, double *out) { IQHOST_TRY(((PhyloTree *)h)->fetchPatternLh(out)); }
 int iqhost_compute_pattern_likelihood(void *h, double *out) { IQHOST_TRY(((PhyloTree *)h)->computePatternLikelihood(out)); }
+int iqhost_compute_pattern_lh_cat(void *h, double *out) { IQHOST_TRY(((PhyloTree *)h)->computePatternLhCat(out)); }
 int iqhost_set_boot_samples(void *h, const float *samples, int nsamples) {
     IQHOST_TRY(((PhyloTree *)h)->setBootSamples(samples, nsamples));
 }

@@ -934,6 +934,15 @@ void PhyloTree::computePatternLikelihood(double *ptn_lh) {
           "iqhip_fetch_pattern_lh_scaled");
 }
 
+void PhyloTree::computePatternLhCat(double *ptn_lh_cat) {
+    if (!engine) throw std::runtime_error("no engine");
+    if (!current_it) throw std::runtime_error("computePatternLhCat before computeLikelihood");
+    double df, ddf;
+    theta_computed = false;
+    computeLikelihoodDerv(current_it, current_it_back->node, df, ddf);  // (re)builds theta of current_it
+    check(iqhip_pattern_lh_cat(engine, current_it->length, ptn_lh_cat), "iqhip_pattern_lh_cat");
+}
+
 void PhyloTree::setBootSamples(const float *samples, int nsamples) {
     if (!engine) throw std::runtime_error("no engine");
     pushInputs();

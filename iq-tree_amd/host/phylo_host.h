@@ -166,6 +166,8 @@ public:
     // computePatternLikelihood: lnL per pattern of the last computeLikelihood(), scaling events of
     // both ends of current_it put back -- computed on the device, one D2H of nptn doubles
     void computePatternLikelihood(double *ptn_lh);
+    // _pattern_lh_cat[ptn*ncat + c] of the current branch (phylotree.cpp:1119-1124 -> scalar kernels), unscaled
+    void computePatternLhCat(double *ptn_lh_cat);
     // UFBoot: boot_samples uploaded once; computeRELL = saveCurrentTree's dot products, on the device
     void setBootSamples(const float *samples /*[nsamples][nptn]*/, int nsamples);
     void computeRELL(std::vector<double> &rell);

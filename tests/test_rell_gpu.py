@@ -121,3 +121,20 @@ def test_rell_throughput_shape(pkg, synth, oracle):
     r2 = t.compute_rell()
     assert np.array_equal(r1, r2)
     np.testing.assert_allclose(r1, w.astype(np.float64) @ t.compute_pattern_likelihood(), rtol=1e-13)
+
+
+@pytest.mark.parametrize("n,ncat,seq_type", [(4, 4, 0), (20, 4, 1), (64, 1, 2)])
+def test_pattern_lh_cat(pkg, synth, oracle, n, ncat, seq_type):
+    """_pattern_lh_cat of the scalar kernels (phylotreesse.cpp:1190-1237), the input of the empirical-Bayes
+    site rates (model/rategamma.cpp:241-262): per category likelihoods of the current branch."""
+    t, ot, model, pat, freq = make_case(synth, oracle, pkg, 10, 300, n, ncat, 5100 + n, seq_type=seq_type, missing=0.02)
+    lnl = t.compute_likelihood()
+    a, b = t.current_branch()
+    cat = t.compute_pattern_lh_cat()
+    th, _ = ot.theta(a, b)
+    ln = ot.length(a, b)
+    val = (np.exp(np.outer(model.rates * ln, model.eval)) * model.props[:, None]).reshape(-1)     # [c][i]
+    expect = (th * val[None, :]).reshape(th.shape[0], ncat, n).sum(axis=2)
+    np.testing.assert_allclose(cat, expect, rtol=1e-10, atol=1e-300)
+    _, oplh = ot.branch_lnl(a, b)
+    np.testing.assert_allclose(np.log(cat.sum(axis=1)), oplh, rtol=1e-9)      # no invariant sites in this model
