@@ -140,6 +140,8 @@ def libiqhost():
     lib.iqhost_destroy.restype = None
     lib.iqhost_set_alignment.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_uint8), dp, dp]
     lib.iqhost_set_ascertainment.argtypes = [vp, C.c_int64, C.c_double]
+    lib.iqhost_set_ptn_freq.argtypes = [vp, dp]
+    lib.iqhost_set_ptn_invar.argtypes = [vp, dp]
     lib.iqhost_set_model.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp]
     lib.iqhost_set_mixture_model.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), dp, dp, dp, dp, dp]
     lib.iqhost_set_mem_mode.argtypes = [vp, C.c_int]
@@ -271,6 +273,16 @@ class PhyloTree:
         self._chk(self.lib.iqhost_set_alignment(self.h, nstates, seq_type, self.nptn,
                                                 states.ctypes.data_as(C.POINTER(C.c_uint8)),
                                                 _dptr(f), _dptr(iv)))
+
+    def set_ptn_freq(self, ptn_freq):
+        f = np.ascontiguousarray(ptn_freq, dtype=np.float64)
+        assert f.size == self.nptn
+        self._chk(self.lib.iqhost_set_ptn_freq(self.h, _dptr(f)))
+
+    def set_ptn_invar(self, ptn_invar):
+        f = np.ascontiguousarray(ptn_invar, dtype=np.float64)
+        assert f.size == self.nptn
+        self._chk(self.lib.iqhost_set_ptn_invar(self.h, _dptr(f)))
 
     def set_ascertainment(self, n_unobserved, nsites):
         """+ASC: the last n_unobserved patterns of set_alignment are the unobserved constant patterns."""

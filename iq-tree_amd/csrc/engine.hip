@@ -95,11 +95,6 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     const size_t P = (size_t)e->nptn_pad;
     bool ok = dmalloc(&e->d_states, (size_t)ntaxa * P) == hipSuccess &&
               dmalloc(&e->d_freq, P) == hipSuccess && dmalloc(&e->d_invar, P) == hipSuccess &&
-              dmalloc(&e->d_eval, nstates) == hipSuccess &&
-              dmalloc(&e->d_evec, nstates * nstates) == hipSuccess &&
-              dmalloc(&e->d_inv_evec, nstates * nstates) == hipSuccess &&
-              dmalloc(&e->d_rates, ncat) == hipSuccess && dmalloc(&e->d_props, ncat) == hipSuccess &&
-              dmalloc(&e->d_tip, 256 * (size_t)nstates) == hipSuccess &&
               dmalloc(&e->d_theta, P * e->block) == hipSuccess &&
               dmalloc(&e->d_pattern_lh, P) == hipSuccess;
     e->result_cap = 8 + 16384;  // up to 16384 node updates per submission
@@ -155,10 +150,9 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
         if (s.plh) hipFree(s.plh);
         if (s.sc) hipFree(s.sc);
     }
-    void *ptrs[] = {e->d_states, e->d_freq, e->d_invar, e->d_eval, e->d_evec, e->d_inv_evec,
-                    e->d_rates, e->d_props, e->d_tip, e->d_ops, e->d_slab,
+    void *ptrs[] = {e->d_states, e->d_freq, e->d_invar, e->d_model, e->d_ops, e->d_slab,
                     e->d_theta, e->d_pattern_lh, e->dummy.plh, e->dummy.sc, e->d_newton_partials,
-                    e->d_newton_barrier, e->d_ptn_scaled, e->d_boot, e->d_evalc, e->d_tipc, e->d_cls, e->d_img};
+                    e->d_newton_barrier, e->d_ptn_scaled, e->d_boot, e->d_img};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (e->h_ops) hipHostFree(e->h_ops);
@@ -344,34 +338,43 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
     HIPCHK(hipSetDevice(e->device));
     const int n = e->n, C = e->ncat;
     HIPCHK(hipStreamSynchronize(e->stream));  // previous work may still read the old model
-    // class 0 in the single-class arrays (4-state and pipelined kernels)
-    HIPCHK(hipMemcpy(e->d_eval, eval, sizeof(double) * n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_evec, evec, sizeof(double) * n * n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_inv_evec, inv_evec, sizeof(double) * n * n, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_rates, rates, sizeof(double) * C, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_props, props, sizeof(double) * C, hipMemcpyHostToDevice));
-    {
-        std::vector<double> tip0((size_t)(state_unknown + 1) * n);
-        for (int s = 0; s <= state_unknown; s++)
-            memcpy(&tip0[(size_t)s * n], &tip[((size_t)s * nclass) * n], sizeof(double) * n);
-        HIPCHK(hipMemcpy(e->d_tip, tip0.data(), sizeof(double) * tip0.size(), hipMemcpyHostToDevice));
-    }
-    // per-category expansions
-    std::vector<double> evalc((size_t)C * n), tipc((size_t)(state_unknown + 1) * C * n);
-    for (int c = 0; c < C; c++) memcpy(&evalc[(size_t)c * n], &eval[(size_t)cls[c] * n], sizeof(double) * n);
-    for (int s = 0; s <= state_unknown; s++)
+    // One device block, one copy per model change (the model optimisers call this once per evaluation):
+    // {eval, evec, inv_evec, tip} of class 0 for the 4-state and pipelined kernels, rates, props, the
+    // per-category expansions evalc[c][i], tipc[state][c][i], and the category -> class map.
+    const size_t nst = (size_t)state_unknown + 1;
+    const size_t o_eval = 0, o_evec = o_eval + n, o_ievec = o_evec + (size_t)n * n, o_rates = o_ievec + (size_t)n * n,
+                 o_props = o_rates + C, o_tip = o_props + C, o_evalc = o_tip + nst * n, o_tipc = o_evalc + (size_t)C * n,
+                 o_cls = o_tipc + nst * C * n, total = o_cls + ((size_t)C + 1) / 2;
+    std::vector<double> blk(total, 0.0);
+    memcpy(&blk[o_eval], eval, sizeof(double) * n);
+    memcpy(&blk[o_evec], evec, sizeof(double) * n * n);
+    memcpy(&blk[o_ievec], inv_evec, sizeof(double) * n * n);
+    memcpy(&blk[o_rates], rates, sizeof(double) * C);
+    memcpy(&blk[o_props], props, sizeof(double) * C);
+    for (size_t s = 0; s < nst; s++) memcpy(&blk[o_tip + s * n], &tip[(s * nclass) * n], sizeof(double) * n);
+    for (int c = 0; c < C; c++) memcpy(&blk[o_evalc + (size_t)c * n], &eval[(size_t)cls[c] * n], sizeof(double) * n);
+    for (size_t s = 0; s < nst; s++)
         for (int c = 0; c < C; c++)
-            memcpy(&tipc[((size_t)s * C + c) * n], &tip[((size_t)s * nclass + cls[c]) * n], sizeof(double) * n);
-    if (e->d_tipc) HIPCHK(hipFree(e->d_tipc));
-    e->d_tipc = nullptr;
-    if (!e->d_evalc) HIPCHK(dmalloc(&e->d_evalc, (size_t)C * n));
-    if (!e->d_cls) HIPCHK(hipMalloc((void **)&e->d_cls, sizeof(int) * C));
-    HIPCHK(dmalloc(&e->d_tipc, tipc.size()));
-    HIPCHK(hipMemcpy(e->d_evalc, evalc.data(), sizeof(double) * evalc.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_tipc, tipc.data(), sizeof(double) * tipc.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_cls, cls.data(), sizeof(int) * C, hipMemcpyHostToDevice));
-    if (e->d_img) HIPCHK(hipFree(e->d_img));
-    e->d_img = nullptr;
+            memcpy(&blk[o_tipc + (s * C + c) * n], &tip[(s * nclass + cls[c]) * n], sizeof(double) * n);
+    memcpy(&blk[o_cls], cls.data(), sizeof(int) * C);
+    if (e->d_model && e->model_cap < total) {
+        HIPCHK(hipFree(e->d_model));
+        e->d_model = nullptr;
+    }
+    if (!e->d_model) {
+        HIPCHK(dmalloc(&e->d_model, total));
+        e->model_cap = total;
+    }
+    HIPCHK(hipMemcpy(e->d_model, blk.data(), sizeof(double) * total, hipMemcpyHostToDevice));
+    e->d_eval = e->d_model + o_eval;
+    e->d_evec = e->d_model + o_evec;
+    e->d_inv_evec = e->d_model + o_ievec;
+    e->d_rates = e->d_model + o_rates;
+    e->d_props = e->d_model + o_props;
+    e->d_tip = e->d_model + o_tip;
+    e->d_evalc = e->d_model + o_evalc;
+    e->d_tipc = e->d_model + o_tipc;
+    e->d_cls = reinterpret_cast<int *>(e->d_model + o_cls);
     if (nclass > 1) {
         // MFMA A-operand images of every class for k_traverse_mfma_mix20: [class][U16 | U4 | Ui16 | Ui4][s][lane]
         // (16-row tile: row = lane & 15; 4-row tail: row = 16 + (lane & 3); k = 4s + (lane >> 4)), followed by
@@ -402,7 +405,14 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
             }
         }
         e->img_generic_off = mix_doubles;
-        HIPCHK(dmalloc(&e->d_img, img.size()));
+        if (e->d_img && e->img_cap < img.size()) {
+            HIPCHK(hipFree(e->d_img));
+            e->d_img = nullptr;
+        }
+        if (!e->d_img) {
+            HIPCHK(dmalloc(&e->d_img, img.size()));
+            e->img_cap = img.size();
+        }
         HIPCHK(hipMemcpy(e->d_img, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
     }
     // the pipelined kernels hold one eigen-system in registers / LDS: mixtures take the generic kernel,

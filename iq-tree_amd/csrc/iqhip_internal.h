@@ -132,7 +132,9 @@ struct iqhip_engine {
     double *d_tipc = nullptr;    // [state_unknown+1][ncat][n]
     int *d_cls = nullptr;        // [ncat]
     double *d_img = nullptr;     // mixture A images: mix20 layout, then the generic kernel's (engine.hip)
-    size_t img_generic_off = 0;
+    size_t img_generic_off = 0, img_cap = 0;
+    double *d_model = nullptr;   // the block all model arrays below point into (set_model_common)
+    size_t model_cap = 0;
     bool mfma_pipelined_ok = false;  // (n, ncat) has a pipelined instantiation (used when nclass == 1)
     // UFBoot / RELL (kernels_rell.hip): scaled per-pattern lnL and the bootstrap sample matrix
     double *d_ptn_scaled = nullptr;

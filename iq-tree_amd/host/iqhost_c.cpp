@@ -54,6 +54,8 @@ int iqhost_set_alignment(void *h, int nstates, int seq_type, int64_t nptn, const
                          const double *freq, const double *invar) {
     IQHOST_TRY(((PhyloTree *)h)->setAlignment(nstates, (SeqType)seq_type, nptn, states, freq, invar));
 }
+int iqhost_set_ptn_freq(void *h, const double *f) { IQHOST_TRY(((PhyloTree *)h)->setPtnFreq(f)); }
+int iqhost_set_ptn_invar(void *h, const double *v) { IQHOST_TRY(((PhyloTree *)h)->setPtnInvar(v)); }
 int iqhost_set_ascertainment(void *h, int64_t n_unobserved, double nsites) {
     IQHOST_TRY(((PhyloTree *)h)->setAscertainment(n_unobserved, nsites));
 }

@@ -264,14 +264,26 @@ void PhyloTree::setAlignment(int nstates, SeqType st, int64_t nptn_, const uint8
     aln_states.assign(states, states + (size_t)leafNum * nptn);
     ptn_freq.assign(freq, freq + nptn);
     ptn_invar.assign(invar, invar + nptn);
-    inputs_dirty = true;
+    inputs_dirty = aln_dirty = true;
+}
+
+void PhyloTree::setPtnFreq(const double *f) {
+    if (nptn <= 0) throw std::runtime_error("setAlignment first");
+    ptn_freq.assign(f, f + nptn);
+    inputs_dirty = weights_dirty = true;
+}
+
+void PhyloTree::setPtnInvar(const double *v) {
+    if (nptn <= 0) throw std::runtime_error("setAlignment first");
+    ptn_invar.assign(v, v + nptn);
+    inputs_dirty = weights_dirty = true;
 }
 
 void PhyloTree::setAscertainment(int64_t n_unobs, double nsites) {
     if (n_unobs < 0 || n_unobs >= nptn) throw std::runtime_error("setAscertainment: bad pattern count");
     n_unobserved = n_unobs;
     asc_nsites = nsites;
-    inputs_dirty = true;
+    inputs_dirty = aln_dirty = true;
 }
 
 void PhyloTree::setModel(int ncat_, const double *eval, const double *evec, const double *inv_evec,
@@ -295,7 +307,7 @@ void PhyloTree::setMixtureModel(int nclass, int ncat_, const int *cat_class, con
     m_cat_class.assign(ncat, 0);
     if (nclass > 1) m_cat_class.assign(cat_class, cat_class + ncat);
     computeTipPartialLikelihood();
-    inputs_dirty = true;
+    inputs_dirty = model_dirty = true;
     theta_computed = false;
 }
 
@@ -344,7 +356,7 @@ void PhyloTree::attachEngine(int device) {
     if (engine) throw std::runtime_error("engine already attached");
     if (m_eval.empty() || aln_states.empty()) throw std::runtime_error("setAlignment and setModel first");
     check(iqhip_create(&engine, device, num_states, ncat, nptn, leafNum), "iqhip_create");
-    inputs_dirty = true;
+    inputs_dirty = model_dirty = aln_dirty = true;
     pushInputs();
     // the reference's arena: leafNum-2 vectors (LM_PER_NODE) or 3*leafNum-6 (phylotree.cpp:867-873)
     int nvec = (lh_mem_save == LM_PER_NODE) ? (leafNum - 2) : (3 * leafNum - 6);
@@ -353,6 +365,8 @@ void PhyloTree::attachEngine(int device) {
 
 void PhyloTree::pushInputs() {
     if (!engine || !inputs_dirty) return;
+    // a model change re-sends the model only: the alignment (megabytes of state rows) stays where it is
+    if (model_dirty) {
     if (nmixture > 1)
         check(iqhip_set_mixture_model(engine, nmixture, m_cat_class.data(), m_eval.data(), m_evec.data(),
                                       m_inv_evec.data(), m_rates.data(), m_props.data(), STATE_UNKNOWN,
@@ -362,10 +376,16 @@ void PhyloTree::pushInputs() {
         check(iqhip_set_model(engine, m_eval.data(), m_evec.data(), m_inv_evec.data(), m_rates.data(),
                               m_props.data(), STATE_UNKNOWN, tip_partial_lh.data()),
               "iqhip_set_model");
-    check(iqhip_set_alignment(engine, aln_states.data(), ptn_freq.data(), ptn_invar.data()),
-          "iqhip_set_alignment");
-    check(iqhip_set_ascertainment(engine, n_unobserved, asc_nsites), "iqhip_set_ascertainment");
-    inputs_dirty = false;
+    }
+    if (aln_dirty) {
+        check(iqhip_set_alignment(engine, aln_states.data(), ptn_freq.data(), ptn_invar.data()),
+              "iqhip_set_alignment");
+        check(iqhip_set_ascertainment(engine, n_unobserved, asc_nsites), "iqhip_set_ascertainment");
+    } else if (weights_dirty) {
+        check(iqhip_set_ptn_freq(engine, ptn_freq.data()), "iqhip_set_ptn_freq");
+        check(iqhip_set_ptn_invar(engine, ptn_invar.data()), "iqhip_set_ptn_invar");
+    }
+    inputs_dirty = model_dirty = aln_dirty = weights_dirty = false;
 }
 
 // =========================================================================================

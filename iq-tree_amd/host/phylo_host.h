@@ -96,6 +96,10 @@ public:
     // +ASC (ModelFactory::unobserved_ptns, model/modelfactory.cpp:359-370): the last n_unobserved
     // patterns of setAlignment are the unobserved constant patterns; nsites = aln->getNSite()
     void setAscertainment(int64_t n_unobserved, double nsites);
+    // new pattern weights / invariant-site terms on an attached engine (computePtnFreq / computePtnInvar,
+    // phylotreesse.cpp:531-569: the reference recomputes them with every model change)
+    void setPtnFreq(const double *ptn_freq);
+    void setPtnInvar(const double *ptn_invar);
     int64_t n_unobserved = 0;
     double asc_nsites = 0.0;
     void setModel(int ncat, const double *eval, const double *evec, const double *inv_evec,
@@ -211,7 +215,8 @@ private:
     AllReduceHook allreduce_hook = nullptr;
     void *allreduce_ctx = nullptr;
     bool dry_run = false;
-    bool inputs_dirty = true;
+    bool inputs_dirty = true;   // anything to push before the next submission
+    bool model_dirty = true, aln_dirty = true, weights_dirty = false;
     uint64_t next_key = 1;
     uint64_t nni_keys[6] = {0, 0, 0, 0, 0, 0};  // nni_partial_lh scratch (phylotree.cpp:852-860)
     std::vector<uint8_t> aln_states;

@@ -723,3 +723,29 @@ def test_lane_split_gives_identical_vectors(pkg, synth, oracle, ncat, ntaxa, kw,
     assert np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]) and x[3] == y[3]
     np.testing.assert_allclose(x[4], y[4], rtol=1e-13)
     assert x[5] == y[5]                     # theta / derivative kernels are not affected by the traversal mapping
+
+
+def test_invariant_site_proportion_changes_on_an_attached_engine(pkg, synth, oracle):
+    """+I optimisation (model/rateinvar.cpp -> computePtnInvar, phylotreesse.cpp:543-569): a new p_invar means new
+    rates, proportions AND ptn_invar; only the model block and the two per-pattern weight arrays travel, the state
+    rows stay on the device."""
+    t, ot, model, pat, freq = make_case(synth, oracle, pkg, 10, 500, 4, 4, 1234, pinvar=0.1)
+    ref, _ = ot.likelihood()
+    assert abs(t.compute_likelihood() - ref) <= LNL_RTOL * abs(ref)
+    for pinv in (0.3, 0.05):
+        m2 = synth.gtr_model(alpha=0.9, ncat=4, pinvar=pinv)
+        inv2 = synth.ptn_invar_for(pat, m2)
+        t.set_model(m2)
+        t.set_ptn_invar(inv2)
+        t.clear_all_partial_lh()
+        ot.set_model(m2)
+        ot.invar = np.ascontiguousarray(inv2, dtype=np.float64)
+        ot.clear()
+        ref2, _ = ot.likelihood()
+        assert abs(t.compute_likelihood() - ref2) <= LNL_RTOL * abs(ref2)
+    f2 = np.roll(freq, 7)
+    t.set_ptn_freq(f2)
+    a, b = t.current_branch()
+    ot.freq = np.ascontiguousarray(f2, dtype=np.float64)
+    ot.clear()
+    assert abs(t.compute_likelihood_branch(a, b) - ot.branch_lnl(a, b)[0]) <= LNL_RTOL * abs(ref2)
