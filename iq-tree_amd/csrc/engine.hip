@@ -120,7 +120,8 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
             e->num_cus = cus;
         ok = dmalloc(&e->d_newton_partials, (size_t)4 * e->num_cus) == hipSuccess &&
-             dmalloc(&e->d_newton_barrier, 1) == hipSuccess;
+             dmalloc(&e->d_newton_barrier, 2) == hipSuccess;
+        if (ok) hipMemsetAsync(e->d_newton_barrier, 0, 2 * sizeof(unsigned int), e->stream);
         if (!ok) {
             iqhip_destroy(e);
             return fail(IQHIP_ERR_NOMEM, "iqhip_create: device allocation failed");

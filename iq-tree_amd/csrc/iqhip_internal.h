@@ -142,7 +142,8 @@ struct iqhip_engine {
     int nboot = 0;
     double *d_result_own = nullptr, *d_result = nullptr;
     double *d_newton_partials = nullptr;   // [2][num_cus][2]
-    unsigned int *d_newton_barrier = nullptr;
+    unsigned int *d_newton_barrier = nullptr;  // [2], used alternately by consecutive k_newton launches
+    unsigned int newton_launches = 0;
     int num_cus = 256;
     int result_cap = 0;
     // pinned host staging

@@ -21,7 +21,8 @@ struct NewtonArgs {
     const double *freq;
     const double *invar;
     double *partials;        // [2 parities][grid][2]
-    unsigned int *barrier;   // monotonic arrival counter (zeroed before the launch)
+    unsigned int *barrier;   // arrival counter of this launch (zero at its start), counts up over the epochs
+    unsigned int *barrier_next;  // the next launch's counter
     double *out;             // {optx, d2l, nsteps, status}
     int64_t ntiles;          // tiles of `tile` patterns
     int64_t nptn;
@@ -97,6 +98,9 @@ __global__ __launch_bounds__(256) void k_newton(const NewtonArgs A) {
     __shared__ double s_bcast[2];
     __shared__ int s_fail;
     if (threadIdx.x == 0) s_fail = 0;
+    // the arrival counters of consecutive launches alternate; this launch clears the next one's
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(A.barrier_next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     unsigned int epoch = 0;
     // f = -dlnL/dt, df = -d2lnL/dt2 at x (phylotree.cpp:2135-2146)
@@ -115,19 +119,19 @@ __global__ __launch_bounds__(256) void k_newton(const NewtonArgs A) {
         if (gridDim.x > 1) {
             double *slot = A.partials + (size_t)(epoch & 1) * gridDim.x * 2;
             if (threadIdx.x == 0) {
-                slot[2 * blockIdx.x] = pdf;
-                slot[2 * blockIdx.x + 1] = pddf;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                // The partials travel as agent-scope (write-through) stores and are read back with agent-scope
+                // loads; no release / acquire fence -- a fence writes back and invalidates the XCD's L2, i.e.
+                // throws away the theta slice this workgroup re-reads in every Newton step.
+                __hip_atomic_store(&slot[2 * blockIdx.x], pdf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&slot[2 * blockIdx.x + 1], pddf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_fetch_add(A.barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned int target = (epoch + 1) * gridDim.x;
                 long spins = 0;
                 while (__hip_atomic_load(A.barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(1);
                     if (++spins > 50000000L) { s_fail = 1; break; }  // never hang the GPU
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();
             // fixed-order sum of the workgroup partials by wave 0 (identical on every workgroup)
@@ -211,7 +215,6 @@ hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, d
     A.freq = e->d_freq;
     A.invar = e->d_invar;
     A.partials = e->d_newton_partials;
-    A.barrier = e->d_newton_barrier;
     A.out = out;
     A.ntiles = e->ntiles;
     A.nptn = e->nptn;
@@ -226,8 +229,9 @@ hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, d
     // one workgroup per CU at most: every workgroup must be resident for the grid barrier
     int64_t wgs = (e->ntiles + 3) / 4;
     int grid = (int)(wgs < 1 ? 1 : (wgs > e->num_cus ? e->num_cus : wgs));
-    hipError_t s = hipMemsetAsync(e->d_newton_barrier, 0, sizeof(unsigned int), e->stream);
-    if (s != hipSuccess) return s;
+    A.barrier = e->d_newton_barrier + (e->newton_launches & 1);
+    A.barrier_next = e->d_newton_barrier + ((e->newton_launches + 1) & 1);
+    e->newton_launches++;
     const size_t lds = (size_t)(3 * e->block + 8) * sizeof(double);
     hipLaunchKernelGGL(k_newton, dim3(grid), dim3(256), lds, e->stream, A);
     return hipGetLastError();
