@@ -816,7 +816,7 @@ static void timing_end(iqhip_engine *e) {
 
 // enqueue: plan upload, K1, fused traversal (+ optional root lnL), fixed-order reduction
 static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, bool has_root,
-                           iqhip_branch_end a, iqhip_branch_end b, double len) {
+                           iqhip_branch_end a, iqhip_branch_end b, double len, bool skip_reduce = false) {
     int rc = check_ready(e);
     if (rc) return rc;
     if (nops < 0 || (nops > 0 && !ops)) return fail(IQHIP_ERR_INVALID, "bad ops array");
@@ -843,7 +843,7 @@ static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, 
     if (e->timing) e->tev_launches += (e->plan_nunits > 0) ? 2 : 1;
     if (e->mfma && has_root) HIPCHK(launch_stream_mfma(e, 0, &br, br.len, nwaves));
     if (has_root) HIPCHK(launch_reduce(e, 0, 2 + nops, nwaves));
-    else HIPCHK(launch_reduce(e, 2, nops, nwaves));
+    else if (!skip_reduce) HIPCHK(launch_reduce(e, 2, nops, nwaves));
     e->last_nops = nops;
     return IQHIP_OK;
 }
@@ -1006,20 +1006,20 @@ extern "C" int iqhip_optimize_branch(iqhip_engine *e, const iqhip_node_op *ops, 
     if (e && e->n_unobs > 0) return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_optimize_branch: +ASC uses iqhip_derv");
     iqhip_branch_end none = {0, -1, 0};
     int rc = IQHIP_OK;
-    if (nops > 0) rc = submit_traverse(e, ops, nops, false, none, none, 0.0);
+    // two launches per branch: the pending node updates, then one kernel that sums their sum_scale rows,
+    // builds theta during its first derivative evaluation and runs the whole Newton-Raphson loop
+    if (nops > 0) rc = submit_traverse(e, ops, nops, false, none, none, 0.0, /*skip_reduce=*/true);
     else rc = check_ready(e);
     if (rc) return rc;
     if (nops + 6 > e->result_cap) return fail(IQHIP_ERR_INVALID, "too many node updates in one submission");
     DevBranch br;
     rc = build_branch(e, a, b, 0.0, -1, &br);
     if (rc) return rc;
-    if (e->mfma) HIPCHK(launch_stream_mfma(e, 1, &br, 0.0, (int)e->ntiles));
-    else HIPCHK(launch_theta4(e, br));
     e->theta_valid = true;
     e->theta_a_sc = br.a_sc;
     e->theta_b_sc = br.b_sc;
     double *out = e->d_result + 2 + nops;
-    HIPCHK(launch_newton(e, xguess, x1, x2, xacc, max_steps, out));
+    HIPCHK(launch_newton(e, xguess, x1, x2, xacc, max_steps, out, &br, nops, (int)e->ntiles * e->lane_split));
     rc = read_result(e, 2 + nops + 4);
     if (rc) return rc;
     if (sum_scale)

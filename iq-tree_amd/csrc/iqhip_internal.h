@@ -182,8 +182,11 @@ hipError_t launch_lnl_theta4(iqhip_engine *e, double len, int nwaves);
 hipError_t launch_reduce(iqhip_engine *e, int first_row, int nrows, int nwaves);
 
 // kernels_newton.hip
+// build_from != nullptr: the first evaluation also builds theta from that branch; reduce_rows > 0: the
+// sum_scale rows [2, 2 + reduce_rows) of the slab are summed into the result vector first
 hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps,
-                         double *out);
+                         double *out, const DevBranch *build_from = nullptr, int reduce_rows = 0,
+                         int reduce_nwaves = 0);
 
 // kernels_rell.hip
 hipError_t launch_pattern_lh_scaled(iqhip_engine *e, const int16_t *sc_a, const int16_t *sc_b, double *out);

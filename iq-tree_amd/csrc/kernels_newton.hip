@@ -24,6 +24,14 @@ struct NewtonArgs {
     unsigned int *barrier;   // arrival counter of this launch (zero at its start), counts up over the epochs
     unsigned int *barrier_next;  // the next launch's counter
     double *out;             // {optx, d2l, nsteps, status}
+    // fused front end (iqhip_optimize_branch): the first evaluation builds theta = a .* b (phylokernel.h:535-573)
+    // while it accumulates, and the sum_scale rows of the preceding node updates are reduced here
+    int build;               // 1: theta is written by the first evaluation from `br`
+    DevBranch br;
+    const double *tipc;      // [state][ncat][n]
+    const double *slab;      // wave partials of the node updates
+    double *result;          // result vector (rows 2.. receive the sums)
+    int nrows, nwaves;
     int64_t ntiles;          // tiles of `tile` patterns
     int64_t nptn;
     int n, ncat, mfma;
@@ -38,6 +46,7 @@ __device__ __forceinline__ double wsum(double v) {
 }
 
 // sum over this workgroup's patterns of f*df_ptn and f*ddf_ptn at the val arrays in LDS
+template <bool BUILD>
 __device__ __forceinline__ void wg_partial(const NewtonArgs &A, const double *s_v0, const double *s_v1,
                                            const double *s_v2, double *s_red, double &odf, double &oddf) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -51,8 +60,23 @@ __device__ __forceinline__ void wg_partial(const NewtonArgs &A, const double *s_
             ptn = tile * 64 + lane;
             mine = ptn < A.nptn;
             const double2 *p = reinterpret_cast<const double2 *>(A.theta + tile * (64 * B)) + lane;
+            const double2 *pb = nullptr, *pa = nullptr;
+            const double *tp = nullptr;
+            if (BUILD) {
+                pb = reinterpret_cast<const double2 *>(A.br.b + tile * (64 * B)) + lane;
+                if (A.br.a_kind == CHILD_LEAF) tp = A.tipc + (size_t)A.br.a_states[ptn] * B;
+                else pa = reinterpret_cast<const double2 *>(A.br.a + tile * (64 * B)) + lane;
+            }
             for (int j = 0; j < B / 2; j++) {
-                const double2 t = p[j * 64];
+                double2 t;
+                if (BUILD) {
+                    const double2 bv = pb[j * 64];
+                    const double2 av = tp ? make_double2(tp[2 * j], tp[2 * j + 1]) : pa[j * 64];
+                    t = make_double2(av.x * bv.x, av.y * bv.y);
+                    const_cast<double2 *>(p)[j * 64] = t;
+                } else {
+                    t = p[j * 64];
+                }
                 lh = fma(s_v0[2 * j], t.x, lh); lh = fma(s_v0[2 * j + 1], t.y, lh);
                 d1 = fma(s_v1[2 * j], t.x, d1); d1 = fma(s_v1[2 * j + 1], t.y, d1);
                 d2 = fma(s_v2[2 * j], t.x, d2); d2 = fma(s_v2[2 * j + 1], t.y, d2);
@@ -62,8 +86,20 @@ __device__ __forceinline__ void wg_partial(const NewtonArgs &A, const double *s_
             ptn = tile * 16 + p;
             mine = (g == 0) && ptn < A.nptn;
             const double *th = A.theta + (size_t)tile * 16 * B;
+            const double *bv = nullptr, *av = nullptr, *tp = nullptr;
+            if (BUILD) {
+                bv = A.br.b + (size_t)tile * 16 * B;
+                if (A.br.a_kind == CHILD_LEAF) tp = A.tipc + (size_t)A.br.a_states[ptn] * B;
+                else av = A.br.a + (size_t)tile * 16 * B;
+            }
             for (int e = g; e < B; e += 4) {
-                const double t = th[(size_t)e * 16 + p];
+                double t;
+                if (BUILD) {
+                    t = (tp ? tp[e] : av[(size_t)e * 16 + p]) * bv[(size_t)e * 16 + p];
+                    const_cast<double *>(th)[(size_t)e * 16 + p] = t;
+                } else {
+                    t = th[(size_t)e * 16 + p];
+                }
                 lh = fma(s_v0[e], t, lh);
                 d1 = fma(s_v1[e], t, d1);
                 d2 = fma(s_v2[e], t, d2);
@@ -102,7 +138,26 @@ __global__ __launch_bounds__(256) void k_newton(const NewtonArgs A) {
     if (blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_store(A.barrier_next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
+    // sum_scale rows of the node updates that ran just before (k_reduce's order: 256 threads, LDS tree)
+    if (A.nrows > 0) {
+        __shared__ double s_rr[256];
+        for (int r = blockIdx.x; r < A.nrows; r += gridDim.x) {
+            const double *row = A.slab + (size_t)(2 + r) * A.nwaves;
+            double acc = 0.0;
+            for (int i = threadIdx.x; i < A.nwaves; i += 256) acc += row[i];
+            s_rr[threadIdx.x] = acc;
+            __syncthreads();
+#pragma unroll
+            for (int o = 128; o > 0; o >>= 1) {
+                if ((int)threadIdx.x < o) s_rr[threadIdx.x] += s_rr[threadIdx.x + o];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) A.result[2 + r] = s_rr[0];
+            __syncthreads();
+        }
+    }
     unsigned int epoch = 0;
+    bool first = true;
     // f = -dlnL/dt, df = -d2lnL/dt2 at x (phylotree.cpp:2135-2146)
     auto eval_at = [&](double x, double &f, double &df) {
         for (int t = threadIdx.x; t < B; t += 256) {
@@ -115,7 +170,9 @@ __global__ __launch_bounds__(256) void k_newton(const NewtonArgs A) {
         }
         __syncthreads();
         double pdf, pddf;
-        wg_partial(A, s_v0, s_v1, s_v2, s_red, pdf, pddf);
+        if (A.build && first) wg_partial<true>(A, s_v0, s_v1, s_v2, s_red, pdf, pddf);
+        else wg_partial<false>(A, s_v0, s_v1, s_v2, s_red, pdf, pddf);
+        first = false;
         if (gridDim.x > 1) {
             double *slot = A.partials + (size_t)(epoch & 1) * gridDim.x * 2;
             if (threadIdx.x == 0) {
@@ -206,8 +263,15 @@ __global__ __launch_bounds__(256) void k_newton(const NewtonArgs A) {
 }
 
 hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps,
-                         double *out) {
+                         double *out, const DevBranch *build_from, int reduce_rows, int reduce_nwaves) {
     NewtonArgs A;
+    A.build = build_from ? 1 : 0;
+    A.br = build_from ? *build_from : DevBranch{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.0};
+    A.tipc = e->d_tipc;
+    A.slab = e->d_slab;
+    A.result = e->d_result;
+    A.nrows = reduce_rows;
+    A.nwaves = reduce_nwaves;
     A.theta = e->d_theta;
     A.eval = e->d_evalc;
     A.rates = e->d_rates;
