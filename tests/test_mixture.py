@@ -117,3 +117,36 @@ def test_mixture_model_switching_and_limits(pkg, synth, oracle):
     t4.set_model(m4)
     with pytest.raises(pkg.HostError, match="20 states"):
         t4.attach_engine(0)
+
+
+@pytest.mark.gpu
+def test_hip_mixture_with_ascertainment_rell_and_staged_plans(pkg, synth, oracle, monkeypatch):
+    """combinations: mixture + ASC (variable sites only), mixture + RELL, mixture under forced plan staging."""
+    from test_parity_gpu import LNL_RTOL
+    model = synth.mixture_model(20, 3, 91, ncat=2)
+    nwk = synth.random_tree_newick(14, 92)
+    st = synth.simulate_alignment(nwk, model.classes[0], 400, 93)
+    st = st[:, [s for s in range(st.shape[1]) if len(set(st[:, s].tolist())) > 1]]
+    pat, freq = synth.compress_patterns(st)
+    nsite = int(freq.sum())
+    pat_a = np.concatenate([pat, np.tile(np.arange(20, dtype=np.uint8), (14, 1))], axis=1)
+    freq_a = np.concatenate([freq, np.zeros(20)])
+    for split in ("0", "4"):
+        monkeypatch.setenv("IQHIP_SPLIT", split)
+        t = pkg.PhyloTree(nwk)
+        t.set_alignment(20, 1, pat_a, freq_a)
+        t.set_ascertainment(20, nsite)
+        t.set_model(model)
+        t.attach_engine(0)
+        ot = oracle.OracleTree(nwk, 20, 1, pat_a, freq_a, None, model, n_unobs=20, nsites=nsite)
+        ref, (a, b) = ot.likelihood()
+        lnl = t.compute_likelihood()
+        assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+        df, ddf = t.compute_likelihood_derv(a, b)
+        odf, oddf = ot.derv(a, b)
+        assert abs(df - odf) <= 1e-8 * max(1.0, abs(odf)) and abs(ddf - oddf) <= 1e-8 * abs(oddf)
+        w = np.vstack([freq_a, np.roll(freq_a[:-20], 3).tolist() + [0.0] * 20]).astype(np.float32)
+        t.set_boot_samples(w)
+        r = t.compute_rell()
+        plh = t.compute_pattern_likelihood()
+        assert abs(r[0] - lnl) <= 1e-9 * abs(lnl) and abs(r[1] - np.dot(w[1].astype(np.float64), plh)) <= 1e-9 * abs(r[1])

@@ -7,7 +7,7 @@
 #include <vector>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-template <int NFMA, bool LOAD, bool STORE, bool SPREAD>
+template <int NFMA, bool LOAD, bool STORE, bool SPREAD, bool NT = false>
 __global__ __launch_bounds__(256, 2) void probe(double *const *slabs, int nsteps, long ntiles, double *out) {
     const int lane = threadIdx.x & 63;
     const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -38,7 +38,14 @@ __global__ __launch_bounds__(256, 2) void probe(double *const *slabs, int nsteps
         }
         if (STORE && !SPREAD) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) *reinterpret_cast<double2 *>(dst + j * 128) = make_double2(v[2 * j], v[2 * j + 1]);
+            for (int j = 0; j < 8; j++) {
+                if (NT) {
+                    __builtin_nontemporal_store(v[2 * j], dst + j * 128);
+                    __builtin_nontemporal_store(v[2 * j + 1], dst + j * 128 + 1);
+                } else {
+                    *reinterpret_cast<double2 *>(dst + j * 128) = make_double2(v[2 * j], v[2 * j + 1]);
+                }
+            }
         }
     }
     double s = 0;
@@ -46,15 +53,15 @@ __global__ __launch_bounds__(256, 2) void probe(double *const *slabs, int nsteps
     if (s == 12345.678) out[0] = s;
 }
 
-template <int NFMA, bool LOAD, bool STORE, bool SPREAD>
+template <int NFMA, bool LOAD, bool STORE, bool SPREAD, bool NT = false>
 float run(double *const *d_slabs, int nsteps, long ntiles, double *d_out, const char *name) {
     hipEvent_t a, b;
     CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     const int grid = (int)((ntiles + 3) / 4);
-    for (int w = 0; w < 3; w++) hipLaunchKernelGGL((probe<NFMA, LOAD, STORE, SPREAD>), dim3(grid), dim3(256), 0, 0, d_slabs, nsteps, ntiles, d_out);
+    for (int w = 0; w < 3; w++) hipLaunchKernelGGL((probe<NFMA, LOAD, STORE, SPREAD, NT>), dim3(grid), dim3(256), 0, 0, d_slabs, nsteps, ntiles, d_out);
     CHECK(hipEventRecord(a));
     const int reps = 20;
-    for (int w = 0; w < reps; w++) hipLaunchKernelGGL((probe<NFMA, LOAD, STORE, SPREAD>), dim3(grid), dim3(256), 0, 0, d_slabs, nsteps, ntiles, d_out);
+    for (int w = 0; w < reps; w++) hipLaunchKernelGGL((probe<NFMA, LOAD, STORE, SPREAD, NT>), dim3(grid), dim3(256), 0, 0, d_slabs, nsteps, ntiles, d_out);
     CHECK(hipEventRecord(b));
     CHECK(hipEventSynchronize(b));
     float ms; CHECK(hipEventElapsedTime(&ms, a, b));
@@ -77,6 +84,8 @@ int main(int argc, char **argv) {
     float t;
     t = run<0, false, true, false>(d_slabs, nsteps, ntiles, d_out, "stores only (end of step)"); printf("   -> %.2f TB/s\n", mb / t / 1e3);
     run<0, false, true, true>(d_slabs, nsteps, ntiles, d_out, "stores only (spread)");
+    t = run<0, false, true, false, true>(d_slabs, nsteps, ntiles, d_out, "non-temporal stores only (end of step)"); printf("   -> %.2f TB/s\n", mb / t / 1e3);
+    run<256, false, true, false, true>(d_slabs, nsteps, ntiles, d_out, "256 FMA + non-temporal stores at end");
     run<256, false, false, false>(d_slabs, nsteps, ntiles, d_out, "256 FMA/lane/step only");
     run<512, false, false, false>(d_slabs, nsteps, ntiles, d_out, "512 FMA/lane/step only");
     run<256, false, true, false>(d_slabs, nsteps, ntiles, d_out, "256 FMA + stores at end");
