@@ -195,6 +195,28 @@ int iqhip_fetch_scale_num(iqhip_engine *e, uint64_t key, int16_t *out /* nptn */
 int iqhip_fetch_pattern_lh(iqhip_engine *e, double *out /* nptn */);
 int iqhip_fetch_partial(iqhip_engine *e, uint64_t key, double *out /* nptn*block, ref layout */);
 int iqhip_fetch_theta(iqhip_engine *e, double *out /* nptn*block, ref layout */);
+/* Batched branch optimisation: ntasks INDEPENDENT branches in one submission -- the NNI candidates of a tree
+ * (IQTree::evaluateNNIs -> PhyloTree::getBestNNIForBran, phylotree.cpp:2873-3066, evaluates them one after the
+ * other; on the device they run side by side).  Task t first runs its own node updates ops[0..nops) (they may
+ * read any existing vector, must write vectors no other task touches -- the nni_partial_lh scratch buffers,
+ * phylotree.cpp:2901-2924), then optimises the length of branch (a, b) as iqhip_optimize_branch does and
+ * evaluates computeLikelihoodFromBuffer at the optimum.  results[t].lnl excludes the lh_scale_factor terms;
+ * sum_scale receives the per-op values of all tasks, concatenated in task order.  +ASC is not supported. */
+typedef struct iqhip_branch_task {
+    const iqhip_node_op *ops;
+    int32_t nops;
+    int32_t max_steps;
+    iqhip_branch_end a, b;
+    double xguess, x1, x2, xacc;
+} iqhip_branch_task;
+typedef struct iqhip_branch_result {
+    double optx, d2l, lnl;
+    int32_t nsteps;
+    int32_t status; /* 0 ok, 2 non-finite derivative, 3 step limit reached (optx is still the last iterate) */
+} iqhip_branch_result;
+int iqhip_optimize_branch_batch(iqhip_engine *e, const iqhip_branch_task *tasks, int ntasks,
+                                double *sum_scale /* sum of nops, may be NULL */, iqhip_branch_result *results);
+
 /* Consumers of the device-resident _pattern_lh (so -wsl / UFBoot need no full-vector round trip per tree).
  * iqhip_fetch_pattern_lh_scaled: PhyloTree::computePatternLikelihood (phylotree.cpp:1200-1230) for the
  *   branch (a,b) the last lnL evaluation ran on: _pattern_lh + (scale_num_a + scale_num_b)*log(2^-256).

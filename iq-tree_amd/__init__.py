@@ -30,7 +30,7 @@ IQHIP_SYMBOLS = [
     "iqhip_synchronize", "iqhip_fetch_scale_num", "iqhip_fetch_pattern_lh", "iqhip_fetch_partial",
     "iqhip_fetch_theta", "iqhip_upload_partial", "iqhip_timing_enable", "iqhip_timing_read",
     "iqhip_fetch_pattern_lh_scaled", "iqhip_set_boot_samples", "iqhip_rell", "iqhip_rell_async",
-    "iqhip_set_mixture_model", "iqhip_pattern_lh_cat",
+    "iqhip_set_mixture_model", "iqhip_pattern_lh_cat", "iqhip_optimize_branch_batch",
 ]
 
 
@@ -176,6 +176,8 @@ def libiqhost():
     lib.iqhost_optimize_all_branches.argtypes = [vp, C.c_int, C.c_double, C.c_int, dp]
     lib.iqhost_set_branch_bounds.argtypes = [vp, C.c_double, C.c_double]
     lib.iqhost_nni_for_branch.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
+    lib.iqhost_evaluate_nnis_batch.argtypes = [vp, C.POINTER(C.c_int), dp, C.c_int, C.POINTER(C.c_int)]
+    lib.iqhost_compute_all_partial_lh.argtypes = [vp]
     lib.iqhost_tree_string.argtypes = [vp, C.c_char_p, C.c_int]
     lib.iqhost_fetch_scale_num.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int16)]
     lib.iqhost_fetch_partial.argtypes = [vp, C.c_int, C.c_int, dp]
@@ -445,6 +447,22 @@ class PhyloTree:
         out = np.zeros(16)
         self._chk(self.lib.iqhost_nni_for_branch(self.h, a, b, int(nni5), _dptr(out)))
         return [(out[8 * c], int(out[8 * c + 1]), int(out[8 * c + 2]), list(out[8 * c + 3:8 * c + 8])) for c in range(2)]
+
+    def evaluate_nnis_batch(self):
+        """all nni1 candidates (2 per internal branch) in one submission ->
+        list of dict(node1, node2, node1_nei, node2_nei, new_len, newloglh)"""
+        cap = 4 * self.num_nodes
+        ids = np.zeros(4 * cap, dtype=np.int32)
+        vals = np.zeros(2 * cap)
+        n = C.c_int()
+        self._chk(self.lib.iqhost_evaluate_nnis_batch(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)), _dptr(vals), cap,
+                                                      C.byref(n)))
+        return [dict(node1=int(ids[4 * k]), node2=int(ids[4 * k + 1]), node1_nei=int(ids[4 * k + 2]),
+                     node2_nei=int(ids[4 * k + 3]), new_len=float(vals[2 * k]), newloglh=float(vals[2 * k + 1]))
+                for k in range(n.value)]
+
+    def compute_all_partial_lh(self):
+        self._chk(self.lib.iqhost_compute_all_partial_lh(self.h))
 
     def set_branch_bounds(self, lo, hi):
         self._chk(self.lib.iqhost_set_branch_bounds(self.h, lo, hi))

@@ -153,7 +153,8 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
     }
     void *ptrs[] = {e->d_states, e->d_freq, e->d_invar, e->d_model, e->d_ops, e->d_slab,
                     e->d_theta, e->d_pattern_lh, e->dummy.plh, e->dummy.sc, e->d_newton_partials,
-                    e->d_newton_barrier, e->d_ptn_scaled, e->d_boot, e->d_img};
+                    e->d_newton_barrier, e->d_ptn_scaled, e->d_boot, e->d_img, e->d_theta_batch, e->d_batch_partials,
+                    e->d_batch_out, e->d_batch_barriers, e->d_batch_tasks};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (e->h_ops) hipHostFree(e->h_ops);
@@ -501,14 +502,17 @@ static int resolve_child(iqhip_engine *e, uint64_t key, int32_t leaf, int prev_d
     return IQHIP_OK;
 }
 
-static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *last_dst) {
+static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *last_dst,
+                      const std::vector<int> *explicit_segs = nullptr) {
     constexpr int kSentinels = 2;  // >= the kernels' deepest look-ahead (streamed child: 1 op)
     if (nops + 2 > e->result_cap) return fail(IQHIP_ERR_INVALID, "too many node updates in one submission");
     // Same op list as last time and no key created / released / moved since: the descriptors on
     // the device are still the right ones (hot loop 1 re-evaluates one tree many times).
     const size_t in_bytes = sizeof(iqhip_node_op) * (size_t)nops;
+    const std::vector<int> no_segs;
+    const std::vector<int> &segs_in = explicit_segs ? *explicit_segs : no_segs;
     if (nops > 0 && e->last_plan_version == e->keymap_version && e->last_ops_in.size() == in_bytes &&
-        memcmp(e->last_ops_in.data(), ops, in_bytes) == 0 && !e->uploaded_plan.empty()) {
+        memcmp(e->last_ops_in.data(), ops, in_bytes) == 0 && !e->uploaded_plan.empty() && e->last_segs == segs_in) {
         *last_dst = e->last_plan_dst;
         return IQHIP_OK;
     }
@@ -531,7 +535,23 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
     std::vector<std::pair<int, int>> units;  // {begin, nops} in the new order
     int top_begin = 0;
     for (int k = 0; k < nops; k++) order[k] = k;
-    {
+    if (explicit_segs) {
+        // caller-defined independent segments (a batch of branch tasks): one set of workgroups each, no top stage
+        std::unordered_set<uint64_t> dsts;
+        for (int k = 0; k < nops; k++)
+            if (!dsts.insert(ops[k].dst_key).second)
+                return fail(IQHIP_ERR_INVALID, "batched node updates must write distinct vectors");
+        int pos = 0;
+        for (size_t s = 0; s < explicit_segs->size(); s++) {
+            const int n = (*explicit_segs)[s];
+            if (n <= 0) continue;
+            units.push_back({pos, n});
+            for (int q = 0; q < n; q++) seg_of[pos + q] = (int)units.size();
+            pos += n;
+        }
+        if (pos != nops) return fail(IQHIP_ERR_INVALID, "segment sizes do not add up to the op count");
+        top_begin = nops;
+    } else {
         int target = e->split_target;
         const int64_t simds = (int64_t)e->num_cus * 4;
         if (target < 0) {
@@ -768,10 +788,12 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         tab[1] = nops - top_begin;
         for (size_t u = 0; u < units.size(); u++) { tab[2 + 2 * u] = units[u].first; tab[3 + 2 * u] = units[u].second; }
         e->plan_nunits = (int)units.size();
+        e->plan_top_nops = nops - top_begin;
         e->plan_table_off = nops + kSentinels;
     }
     const size_t nbytes = sizeof(DevOp) * (size_t)(nops + kSentinels + table_ops);
     e->last_ops_in.assign((const char *)ops, (const char *)ops + in_bytes);
+    e->last_segs = segs_in;
     e->last_plan_version = e->keymap_version;  // (slabs created while building are included)
     e->last_plan_dst = prev_dst;
     if (e->uploaded_plan.size() == nbytes && memcmp(e->uploaded_plan.data(), e->h_ops, nbytes) == 0)
@@ -816,12 +838,13 @@ static void timing_end(iqhip_engine *e) {
 
 // enqueue: plan upload, K1, fused traversal (+ optional root lnL), fixed-order reduction
 static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, bool has_root,
-                           iqhip_branch_end a, iqhip_branch_end b, double len, bool skip_reduce = false) {
+                           iqhip_branch_end a, iqhip_branch_end b, double len, bool skip_reduce = false,
+                           const std::vector<int> *explicit_segs = nullptr) {
     int rc = check_ready(e);
     if (rc) return rc;
     if (nops < 0 || (nops > 0 && !ops)) return fail(IQHIP_ERR_INVALID, "bad ops array");
     int last_dst = -1;
-    rc = build_plan(e, ops, nops, &last_dst);
+    rc = build_plan(e, ops, nops, &last_dst, explicit_segs);
     if (rc) return rc;
     DevBranch br;
     if (has_root) {
@@ -837,7 +860,9 @@ static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, 
         if (e->mfma) HIPCHK(launch_traverse_mfma(e, table + 2, e->plan_nunits, nwaves));
         else HIPCHK(launch_traverse4(e, table + 2, e->plan_nunits, e->plan_units_have_load, nullptr, nwaves));
     }
-    if (e->mfma) HIPCHK(launch_traverse_mfma(e, table, nops > 0 ? 1 : 0, nwaves));
+    const bool empty_top = e->plan_nunits > 0 && !has_root && e->plan_top_nops == 0;  // explicit segments only
+    if (empty_top) {
+    } else if (e->mfma) HIPCHK(launch_traverse_mfma(e, table, nops > 0 ? 1 : 0, nwaves));
     else HIPCHK(launch_traverse4(e, table, 1, e->plan_has_load, has_root ? &br : nullptr, nwaves));
     timing_end(e);
     if (e->timing) e->tev_launches += (e->plan_nunits > 0) ? 2 : 1;
@@ -1032,6 +1057,101 @@ extern "C" int iqhip_optimize_branch(iqhip_engine *e, const iqhip_node_op *ops, 
     if (optx) *optx = r[0];
     if (d2l) *d2l = r[1];
     if (nsteps) *nsteps = (int)r[2];
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_optimize_branch_batch(iqhip_engine *e, const iqhip_branch_task *tasks, int ntasks,
+                                           double *sum_scale, iqhip_branch_result *results) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    if (!tasks || !results || ntasks < 1) return fail(IQHIP_ERR_INVALID, "bad task array");
+    if (e->n_unobs > 0) return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_optimize_branch_batch: +ASC is not supported");
+    std::vector<iqhip_node_op> all;
+    std::vector<int> segs(ntasks);
+    for (int t = 0; t < ntasks; t++) {
+        const iqhip_branch_task &k = tasks[t];
+        if (k.nops < 0 || (k.nops > 0 && !k.ops)) return fail(IQHIP_ERR_INVALID, "bad ops array in a task");
+        if (!(k.x1 >= 0.0) || !(k.x2 > k.x1) || !(k.xacc > 0.0) || k.max_steps < 1 || !(k.xguess >= 0.0))
+            return fail(IQHIP_ERR_INVALID, "iqhip_optimize_branch_batch: bad bounds / tolerance / step count");
+        segs[t] = k.nops;
+        all.insert(all.end(), k.ops, k.ops + k.nops);
+    }
+    const int total_ops = (int)all.size();
+    if (total_ops + 2 > e->result_cap) return fail(IQHIP_ERR_INVALID, "too many node updates in one submission");
+    iqhip_branch_end none = {0, -1, 0};
+    if (total_ops > 0) {
+        rc = submit_traverse(e, all.data(), total_ops, false, none, none, 0.0, /*skip_reduce=*/false, &segs);
+        if (rc) return rc;
+    }
+    // workgroups per task: every workgroup of a launch must be resident (grid barrier inside each task)
+    const int capacity = e->num_cus * 4;
+    const int wgs_needed = (int)std::max<int64_t>(1, (e->ntiles + 3) / 4);
+    const int chunk = std::min(ntasks, capacity);             // tasks per launch
+    const int G = std::max(1, std::min(wgs_needed, capacity / chunk));
+    const size_t theta_stride = (size_t)e->nptn_pad * e->block;
+    if ((size_t)chunk * theta_stride > e->theta_batch_cap) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->d_theta_batch) hipFree(e->d_theta_batch);
+        e->d_theta_batch = nullptr;
+        e->theta_batch_cap = 0;
+        HIPCHK(dmalloc(&e->d_theta_batch, (size_t)chunk * theta_stride));
+        e->theta_batch_cap = (size_t)chunk * theta_stride;
+    }
+    if (chunk > e->batch_cap) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        void *old[] = {e->d_batch_partials, e->d_batch_out, e->d_batch_barriers, e->d_batch_tasks};
+        for (void *p : old)
+            if (p) hipFree(p);
+        e->d_batch_partials = e->d_batch_out = nullptr;
+        e->d_batch_barriers = nullptr;
+        e->d_batch_tasks = nullptr;
+        e->batch_cap = 0;
+        HIPCHK(dmalloc(&e->d_batch_partials, (size_t)chunk * 4 * capacity));
+        HIPCHK(dmalloc(&e->d_batch_out, (size_t)chunk * 6));
+        HIPCHK(dmalloc(&e->d_batch_barriers, (size_t)2 * chunk));
+        HIPCHK(hipMalloc(&e->d_batch_tasks, newton_task_bytes() * (size_t)chunk));
+        HIPCHK(hipMemsetAsync(e->d_batch_barriers, 0, sizeof(unsigned int) * 2 * chunk, e->stream));
+        e->batch_cap = chunk;
+    }
+    std::vector<char> host_tasks(newton_task_bytes() * (size_t)chunk);
+    std::vector<double> out((size_t)chunk * 6);
+    for (int first = 0; first < ntasks; first += chunk) {
+        const int m = std::min(chunk, ntasks - first);
+        for (int t = 0; t < m; t++) {
+            const iqhip_branch_task &k = tasks[first + t];
+            DevBranch br;
+            rc = build_branch(e, k.a, k.b, 0.0, -1, &br);
+            if (rc) return rc;
+            newton_task_fill(host_tasks.data() + newton_task_bytes() * (size_t)t, br, k.xguess, k.x1, k.x2, k.xacc,
+                             k.max_steps);
+        }
+        HIPCHK(hipMemcpyAsync(e->d_batch_tasks, host_tasks.data(), newton_task_bytes() * (size_t)m,
+                              hipMemcpyHostToDevice, e->stream));
+        const unsigned int parity = e->batch_launches & 1u;
+        e->batch_launches++;
+        HIPCHK(launch_newton_batch(e, e->d_batch_tasks, m, G, e->d_theta_batch, theta_stride, e->d_batch_partials,
+                                   e->d_batch_barriers + (size_t)parity * e->batch_cap,
+                                   e->d_batch_barriers + (size_t)(1u - parity) * e->batch_cap, e->d_batch_out));
+        HIPCHK(hipMemcpyAsync(out.data(), e->d_batch_out, sizeof(double) * 6 * (size_t)m, hipMemcpyDeviceToHost,
+                              e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));  // also: host_tasks / out are reused by the next chunk
+        for (int t = 0; t < m; t++) {
+            const double *o = &out[(size_t)t * 6];
+            iqhip_branch_result &r = results[first + t];
+            r.optx = o[0];
+            r.d2l = o[1];
+            r.nsteps = (int)o[2];
+            r.status = (int)o[3];
+            r.lnl = o[4];
+            if (r.status == 4) return fail(IQHIP_ERR_HIP, "iqhip_optimize_branch_batch: grid barrier timed out");
+        }
+    }
+    if (total_ops > 0) {
+        rc = read_result(e, 2 + total_ops);
+        if (rc) return rc;
+        if (sum_scale)
+            for (int k = 0; k < total_ops; k++) sum_scale[k] = e->h_result[2 + k];
+    }
     return IQHIP_OK;
 }
 

@@ -92,6 +92,8 @@ struct iqhip_engine {
     // first launch, the ops above them ("top") in a second one.  Segment table on the device, after the
     // sentinel descriptors: {top_begin, top_nops, unit1_begin, unit1_nops, ...}
     int plan_nunits = 0;
+    int plan_top_nops = 0;
+    std::vector<int> last_segs;   // explicit segment sizes the cached descriptors were built with
     int plan_table_off = 0;      // DevOp index where the table starts
     bool plan_units_have_load = false;
     int split_target = -1;       // IQHIP_SPLIT: -1 auto, 0 never, n > 0: unit size
@@ -144,6 +146,14 @@ struct iqhip_engine {
     double *d_newton_partials = nullptr;   // [2][num_cus][2]
     unsigned int *d_newton_barrier = nullptr;  // [2], used alternately by consecutive k_newton launches
     unsigned int newton_launches = 0;
+    // batched branch optimisation (iqhip_optimize_branch_batch): per-task theta buffers, partial sums, arrival
+    // counters (two sets, alternating per launch), results and the task descriptors
+    double *d_theta_batch = nullptr, *d_batch_partials = nullptr, *d_batch_out = nullptr;
+    unsigned int *d_batch_barriers = nullptr;
+    void *d_batch_tasks = nullptr;
+    size_t theta_batch_cap = 0;
+    int batch_cap = 0;
+    unsigned int batch_launches = 0;
     int num_cus = 256;
     int result_cap = 0;
     // pinned host staging
@@ -192,6 +202,13 @@ hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, d
 hipError_t launch_pattern_lh_scaled(iqhip_engine *e, const int16_t *sc_a, const int16_t *sc_b, double *out);
 hipError_t launch_rell(iqhip_engine *e, double *out);
 hipError_t launch_pattern_lh_cat(iqhip_engine *e, double len, double *out);
+
+// batched branch optimisation (k_newton_batch); d_tasks: device array of NewtonTask (kernels_newton.hip)
+hipError_t launch_newton_batch(iqhip_engine *e, const void *d_tasks, int ntasks, int G, double *theta_base,
+                               size_t theta_stride, double *partials, unsigned int *barriers, unsigned int *barriers_next,
+                               double *out);
+size_t newton_task_bytes();
+void newton_task_fill(void *dst, const DevBranch &br, double xguess, double x1, double x2, double xacc, int max_steps);
 
 // kernels_mfma.hip (nstates 20 / 64)
 hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs, int nwaves);

@@ -9,6 +9,8 @@
 // A single workgroup needs no grid barrier at all (the common case: real alignments have a few
 // thousand patterns); larger grids use a monotonic-counter barrier (agent-scope release/acquire,
 // bounded spin) with one workgroup per CU.
+#include <string.h>
+
 #include "iqhip_internal.h"
 
 namespace iqhip {
@@ -46,26 +48,29 @@ __device__ __forceinline__ double wsum(double v) {
 }
 
 // sum over this workgroup's patterns of f*df_ptn and f*ddf_ptn at the val arrays in LDS
-template <bool BUILD>
-__device__ __forceinline__ void wg_partial(const NewtonArgs &A, const double *s_v0, const double *s_v1,
+// MODE 0: derivative sums (f*df_ptn, f*ddf_ptn); MODE 1: lnL sum (f*log|lh_ptn|) in odf.  The workgroup is
+// number `wg` of `nwg` that share the patterns of one branch (the whole grid for k_newton).
+template <bool BUILD, int MODE = 0>
+__device__ __forceinline__ void wg_partial(const NewtonArgs &A, const double *theta_c, const DevBranch &br, int wg, int nwg,
+                                           const double *s_v0, const double *s_v1,
                                            const double *s_v2, double *s_red, double &odf, double &oddf) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int B = A.n * A.ncat;
     double adf = 0.0, addf = 0.0;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < A.ntiles; tile += (int64_t)gridDim.x * 4) {
+    for (int64_t tile = (int64_t)wg * 4 + wave; tile < A.ntiles; tile += (int64_t)nwg * 4) {
         double lh = 0.0, d1 = 0.0, d2 = 0.0;
         int64_t ptn;
         bool mine;
         if (!A.mfma) {
             ptn = tile * 64 + lane;
             mine = ptn < A.nptn;
-            const double2 *p = reinterpret_cast<const double2 *>(A.theta + tile * (64 * B)) + lane;
+            const double2 *p = reinterpret_cast<const double2 *>(theta_c + tile * (64 * B)) + lane;
             const double2 *pb = nullptr, *pa = nullptr;
             const double *tp = nullptr;
             if (BUILD) {
-                pb = reinterpret_cast<const double2 *>(A.br.b + tile * (64 * B)) + lane;
-                if (A.br.a_kind == CHILD_LEAF) tp = A.tipc + (size_t)A.br.a_states[ptn] * B;
-                else pa = reinterpret_cast<const double2 *>(A.br.a + tile * (64 * B)) + lane;
+                pb = reinterpret_cast<const double2 *>(br.b + tile * (64 * B)) + lane;
+                if (br.a_kind == CHILD_LEAF) tp = A.tipc + (size_t)br.a_states[ptn] * B;
+                else pa = reinterpret_cast<const double2 *>(br.a + tile * (64 * B)) + lane;
             }
             for (int j = 0; j < B / 2; j++) {
                 double2 t;
@@ -85,12 +90,12 @@ __device__ __forceinline__ void wg_partial(const NewtonArgs &A, const double *s_
             const int p = lane & 15, g = lane >> 4;
             ptn = tile * 16 + p;
             mine = (g == 0) && ptn < A.nptn;
-            const double *th = A.theta + (size_t)tile * 16 * B;
+            const double *th = theta_c + (size_t)tile * 16 * B;
             const double *bv = nullptr, *av = nullptr, *tp = nullptr;
             if (BUILD) {
-                bv = A.br.b + (size_t)tile * 16 * B;
-                if (A.br.a_kind == CHILD_LEAF) tp = A.tipc + (size_t)A.br.a_states[ptn] * B;
-                else av = A.br.a + (size_t)tile * 16 * B;
+                bv = br.b + (size_t)tile * 16 * B;
+                if (br.a_kind == CHILD_LEAF) tp = A.tipc + (size_t)br.a_states[ptn] * B;
+                else av = br.a + (size_t)tile * 16 * B;
             }
             for (int e = g; e < B; e += 4) {
                 double t;
@@ -111,11 +116,15 @@ __device__ __forceinline__ void wg_partial(const NewtonArgs &A, const double *s_
         if (mine) {
             lh += A.invar[ptn];
             const double f = A.freq[ptn];
-            const double inv = 1.0 / fabs(lh);
-            const double dfp = d1 * inv;
-            const double ddfp = fma(-dfp, dfp, d2 * inv);
-            adf = fma(dfp, f, adf);
-            addf = fma(ddfp, f, addf);
+            if (MODE == 1) {
+                adf = fma(log(fabs(lh)), f, adf);
+            } else {
+                const double inv = 1.0 / fabs(lh);
+                const double dfp = d1 * inv;
+                const double ddfp = fma(-dfp, dfp, d2 * inv);
+                adf = fma(dfp, f, adf);
+                addf = fma(ddfp, f, addf);
+            }
         }
     }
     adf = wsum(adf);
@@ -170,8 +179,8 @@ __global__ __launch_bounds__(256) void k_newton(const NewtonArgs A) {
         }
         __syncthreads();
         double pdf, pddf;
-        if (A.build && first) wg_partial<true>(A, s_v0, s_v1, s_v2, s_red, pdf, pddf);
-        else wg_partial<false>(A, s_v0, s_v1, s_v2, s_red, pdf, pddf);
+        if (A.build && first) wg_partial<true>(A, A.theta, A.br, blockIdx.x, gridDim.x, s_v0, s_v1, s_v2, s_red, pdf, pddf);
+        else wg_partial<false>(A, A.theta, A.br, blockIdx.x, gridDim.x, s_v0, s_v1, s_v2, s_red, pdf, pddf);
         first = false;
         if (gridDim.x > 1) {
             double *slot = A.partials + (size_t)(epoch & 1) * gridDim.x * 2;
@@ -260,6 +269,219 @@ __global__ __launch_bounds__(256) void k_newton(const NewtonArgs A) {
         A.out[2] = (double)nsteps;
         A.out[3] = (double)status;
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Batched form: M independent branches (the NNI candidates of a tree, IQTree::evaluateNNIs ->
+// getBestNNIForBran, phylotree.cpp:2873-3066) in ONE launch.  Task t owns workgroups [t*G, (t+1)*G), its own
+// theta buffer, partial-sum slots and arrival counter; inside a task everything is k_newton: theta is built
+// by the first evaluation, every workgroup of the task runs minimizeNewton's control flow redundantly, and a
+// last pass gives the lnL at the optimum (computeLikelihoodFromBuffer).  All M*G workgroups must be resident
+// (the host sizes G for that and splits larger batches).
+// ---------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) NewtonTask {
+    DevBranch br;
+    double xguess, x1, x2, xacc;
+    int32_t max_steps;
+    int32_t _pad[3];
+};
+
+struct NewtonBatchArgs {
+    NewtonArgs c;               // the model / alignment fields are used; theta, br, x*, out are per task
+    const NewtonTask *tasks;
+    double *theta_base;         // [ntasks][theta_stride]
+    size_t theta_stride;
+    double *partials;           // [ntasks][2 parities][G][2]
+    unsigned int *barriers;     // [ntasks] arrival counters of this launch (zero at its start)
+    unsigned int *barriers_next;  // the next launch's counters, cleared here
+    double *out;                // [ntasks][6] = {optx, d2l, nsteps, status, lnl, 0}
+    int G;
+};
+
+__global__ __launch_bounds__(256) void k_newton_batch(const NewtonBatchArgs P) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const NewtonArgs &A = P.c;
+    const int B = A.n * A.ncat;
+    double *s_v0 = smem, *s_v1 = smem + B, *s_v2 = smem + 2 * B, *s_red = smem + 3 * B;  // s_red[8]
+    __shared__ double s_bcast[2];
+    __shared__ int s_fail;
+    const int task = (int)blockIdx.x / P.G, wg = (int)blockIdx.x - task * P.G, G = P.G;
+    const NewtonTask &T = P.tasks[task];
+    double *theta = P.theta_base + (size_t)task * P.theta_stride;
+    double *slots = P.partials + (size_t)task * 4 * G;
+    unsigned int *bar = P.barriers + task;
+    if (threadIdx.x == 0) {
+        s_fail = 0;
+        if (wg == 0) __hip_atomic_store(P.barriers_next + task, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned int epoch = 0;
+    bool first = true;
+    // sums over the task's patterns of (f*df, f*ddf) -- or of f*log|lh| when lnl_pass -- at branch length x
+    auto eval_at = [&](double x, bool lnl_pass, double &r0, double &r1) {
+        for (int t = threadIdx.x; t < B; t += 256) {
+            const int c = t / A.n;
+            const double cof = A.eval[t] * A.rates[c];
+            const double v = exp(cof * x) * A.props[c];
+            s_v0[t] = v;
+            s_v1[t] = cof * v;
+            s_v2[t] = cof * (cof * v);
+        }
+        __syncthreads();
+        double p0, p1;
+        if (lnl_pass) wg_partial<false, 1>(A, theta, T.br, wg, G, s_v0, s_v1, s_v2, s_red, p0, p1);
+        else if (first) wg_partial<true, 0>(A, theta, T.br, wg, G, s_v0, s_v1, s_v2, s_red, p0, p1);
+        else wg_partial<false, 0>(A, theta, T.br, wg, G, s_v0, s_v1, s_v2, s_red, p0, p1);
+        first = false;
+        if (G > 1) {
+            double *slot = slots + (size_t)(epoch & 1) * G * 2;
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(&slot[2 * wg], p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&slot[2 * wg + 1], p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int target = (epoch + 1) * (unsigned int)G;
+                long spins = 0;
+                while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > 50000000L) { s_fail = 1; break; }  // never hang the GPU
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) {  // fixed-order sum of the task's workgroup partials
+                double a = 0.0, b = 0.0;
+                for (int w = threadIdx.x; w < G; w += 64) {
+                    a += __hip_atomic_load(&slot[2 * w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    b += __hip_atomic_load(&slot[2 * w + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                a = wsum(a);
+                b = wsum(b);
+                if (threadIdx.x == 0) { s_bcast[0] = a; s_bcast[1] = b; }
+            }
+            __syncthreads();
+            p0 = s_bcast[0];
+            p1 = s_bcast[1];
+            __syncthreads();
+            epoch++;
+        }
+        r0 = p0;
+        r1 = p1;
+    };
+    auto derv_at = [&](double x, double &f, double &df) {
+        double pdf, pddf;
+        eval_at(x, false, pdf, pddf);
+        if (isnan(pdf) || isinf(pdf)) { pdf = 0.0; pddf = 0.0; }  // phylokernel.h:647-651
+        f = -pdf;
+        df = -pddf;
+    };
+
+    // ---- Optimization::minimizeNewton (optimization.cpp:388-450), same control flow as k_newton
+    double df, dx, f, temp, xh, xl, rts, rts_old, d2l;
+    int nsteps = 1, status = 0;
+    rts = T.xguess;
+    if (rts < T.x1) rts = T.x1;
+    if (rts > T.x2) rts = T.x2;
+    derv_at(rts, f, df);
+    d2l = df;
+    double result = rts;
+    bool done = false;
+    if (!isfinite(f) || !isfinite(df)) { status = 2; done = true; }
+    if (!done && df >= 0.0 && fabs(f) < T.xacc) done = true;
+    if (!done) {
+        if (f < 0.0) { xl = rts; xh = T.x2; } else { xh = rts; xl = T.x1; }
+        dx = fabs(xh - xl);
+        int j;
+        for (j = 1; j <= T.max_steps; j++) {
+            rts_old = rts;
+            if ((df <= 0.0) || (((rts - xh) * df - f) * ((rts - xl) * df - f) >= 0.0)) {
+                dx = 0.5 * (xh - xl);
+                rts = xl + dx;
+                d2l = df;
+                if (xl == rts) { result = rts; break; }
+            } else {
+                dx = f / df;
+                temp = rts;
+                rts -= dx;
+                d2l = df;
+                if (temp == rts) { result = rts; break; }
+            }
+            if (fabs(dx) < T.xacc || (j == T.max_steps)) { result = rts_old; break; }
+            derv_at(rts, f, df);
+            nsteps++;
+            if (!isfinite(f) || !isfinite(df)) { status = 2; result = rts_old; break; }
+            if (df > 0.0 && fabs(f) < T.xacc) { d2l = df; result = rts; break; }
+            if (f < 0.0) xl = rts; else xh = rts;
+        }
+        if (j > T.max_steps) status = 3;
+    }
+    // lnL of the branch at the returned length (computeLikelihoodFromBuffer, phylokernel.h:1022-1192)
+    double lnl, unused;
+    eval_at(result, true, lnl, unused);
+    __syncthreads();
+    if (s_fail) status = 4;
+    if (wg == 0 && threadIdx.x == 0) {
+        double *o = P.out + (size_t)task * 6;
+        o[0] = result;
+        o[1] = d2l;
+        o[2] = (double)nsteps;
+        o[3] = (double)status;
+        o[4] = lnl;
+        o[5] = 0.0;
+    }
+}
+
+size_t newton_task_bytes() { return sizeof(NewtonTask); }
+void newton_task_fill(void *dst, const DevBranch &br, double xguess, double x1, double x2, double xacc, int max_steps) {
+    NewtonTask t;
+    memset(&t, 0, sizeof t);
+    t.br = br;
+    t.xguess = xguess;
+    t.x1 = x1;
+    t.x2 = x2;
+    t.xacc = xacc;
+    t.max_steps = max_steps;
+    memcpy(dst, &t, sizeof t);
+}
+
+hipError_t launch_newton_batch(iqhip_engine *e, const void *d_tasks, int ntasks, int G, double *theta_base,
+                               size_t theta_stride, double *partials, unsigned int *barriers, unsigned int *barriers_next,
+                               double *out) {
+    NewtonBatchArgs P;
+    NewtonArgs &A = P.c;
+    A.theta = nullptr;
+    A.eval = e->d_evalc;
+    A.rates = e->d_rates;
+    A.props = e->d_props;
+    A.freq = e->d_freq;
+    A.invar = e->d_invar;
+    A.partials = nullptr;
+    A.barrier = nullptr;
+    A.barrier_next = nullptr;
+    A.out = nullptr;
+    A.build = 1;
+    A.br = DevBranch{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.0};
+    A.tipc = e->d_tipc;
+    A.slab = nullptr;
+    A.result = nullptr;
+    A.nrows = 0;
+    A.nwaves = 0;
+    A.ntiles = e->ntiles;
+    A.nptn = e->nptn;
+    A.n = e->n;
+    A.ncat = e->ncat;
+    A.mfma = e->mfma ? 1 : 0;
+    A.xguess = A.x1 = A.x2 = A.xacc = 0.0;
+    A.max_steps = 0;
+    P.tasks = static_cast<const NewtonTask *>(d_tasks);
+    P.theta_base = theta_base;
+    P.theta_stride = theta_stride;
+    P.partials = partials;
+    P.barriers = barriers;
+    P.barriers_next = barriers_next;
+    P.out = out;
+    P.G = G;
+    const size_t lds = (size_t)(3 * e->block + 8) * sizeof(double);
+    hipLaunchKernelGGL(k_newton_batch, dim3((unsigned)(ntasks * G)), dim3(256), lds, e->stream, P);
+    return hipGetLastError();
 }
 
 hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps,

@@ -236,6 +236,22 @@ int iqhost_compute_rell(void *h, double *out, int cap) {
 
 // last submitted plan: 7 ints per op {dst_from, dst_to, left_node, right_node, left_leaf, right_leaf, 0}
 // plus 2 doubles per op {left_len, right_len}; dst_from->dst_to is the neighbour that was filled
+// all nni1 candidates of the tree in one submission: out[k*5 + {0..4}] = node1, node2, node1_nei, node2_nei ids,
+// then lens/lnls: newLen[0], newloglh.  Returns the number of candidates in *n.
+int iqhost_evaluate_nnis_batch(void *h, int *ids, double *vals, int cap, int *n) {
+    IQHOST_TRY({
+        std::vector<PhyloTree::NNIMove> mv;
+        ((PhyloTree *)h)->evaluateNNIsBatch(mv);
+        if ((int)mv.size() > cap) throw std::runtime_error("output too small");
+        *n = (int)mv.size();
+        for (size_t k = 0; k < mv.size(); k++) {
+            ids[4 * k] = mv[k].node1; ids[4 * k + 1] = mv[k].node2;
+            ids[4 * k + 2] = mv[k].node1_nei; ids[4 * k + 3] = mv[k].node2_nei;
+            vals[2 * k] = mv[k].newLen[0]; vals[2 * k + 1] = mv[k].newloglh;
+        }
+    });
+}
+int iqhost_compute_all_partial_lh(void *h) { IQHOST_TRY(((PhyloTree *)h)->computeAllPartialLh()); }
 int iqhost_last_plan(void *h, int *ints, double *lens, uint64_t *keys, int cap) {
     PhyloTree *t = (PhyloTree *)h;
     int n = (int)t->last_plan.size();

@@ -929,6 +929,116 @@ PhyloTree::NNIMove PhyloTree::getBestNNIForBran(PhyloNode *node1, PhyloNode *nod
     return moves[0].newloglh > moves[1].newloglh ? moves[0] : moves[1];
 }
 
+void PhyloTree::computeAllPartialLh() {
+    if (lh_mem_save != LM_ALL_BRANCH) throw std::runtime_error("computeAllPartialLh needs LM_ALL_BRANCH");
+    if (!central_partial_lh) initializeAllPartialLh();
+    for (PhyloNode *node : nodes)
+        for (PhyloNeighbor *nb : node->neighbors)
+            if (!nb->node->isLeaf() && (nb->partial_lh_computed & 1) == 0) computePartialLikelihood(nb, node);
+}
+
+void PhyloTree::evaluateNNIsBatch(std::vector<NNIMove> &moves) {
+    if (!engine || dry_run) throw std::runtime_error("evaluateNNIsBatch needs an attached engine");
+    if (allreduce_hook || n_unobserved > 0) throw std::runtime_error("evaluateNNIsBatch: sharded / +ASC runs use getBestNNIForBran");
+    computeAllPartialLh();
+    pushInputs();
+    struct Cand {
+        PhyloNode *node1, *node2;
+        PhyloNeighbor *n1a, *n1b, *n2x, *n2o;  // n1a <-> n2x are swapped
+        iqhip_node_op ops[2];
+    };
+    std::vector<Cand> cands;
+    for (PhyloNode *node1 : nodes)
+        for (PhyloNeighbor *nb12 : node1->neighbors) {
+            PhyloNode *node2 = nb12->node;
+            if (node1->isLeaf() || node2->isLeaf() || node1->id > node2->id) continue;
+            if (node1->degree() != 3 || node2->degree() != 3)
+                throw std::runtime_error("evaluateNNIsBatch needs a binary tree");
+            std::vector<PhyloNeighbor *> s1, s2;
+            for (PhyloNeighbor *nb : node1->neighbors) if (nb->node != node2) s1.push_back(nb);
+            for (PhyloNeighbor *nb : node2->neighbors) if (nb->node != node1) s2.push_back(nb);
+            for (int cnt = 0; cnt < 2; cnt++) {  // phylotree.cpp:2951-2960: first neighbour of node1 against each of node2's
+                Cand c;
+                c.node1 = node1; c.node2 = node2;
+                c.n1a = s1[0]; c.n1b = s1[1]; c.n2x = s2[cnt]; c.n2o = s2[1 - cnt];
+                cands.push_back(c);
+            }
+        }
+    while (nni_batch_keys.size() < 2 * cands.size()) nni_batch_keys.push_back(next_key++);
+    auto child = [&](PhyloNeighbor *nb, uint64_t &key, int32_t &leaf, double &len) {
+        if (nb->node->isLeaf()) { key = 0; leaf = nb->node->id; }
+        else { key = nb->partial_lh; leaf = -1; }
+        len = nb->length;
+    };
+    std::vector<iqhip_branch_task> tasks(cands.size());
+    for (size_t t = 0; t < cands.size(); t++) {
+        Cand &c = cands[t];
+        // after the swap node2's subtree (seen from node1) joins n1a and n2o, node1's joins n2x and n1b
+        memset(c.ops, 0, sizeof c.ops);
+        c.ops[0].dst_key = nni_batch_keys[2 * t];
+        child(c.n1a, c.ops[0].left_key, c.ops[0].left_leaf, c.ops[0].left_len);
+        child(c.n2o, c.ops[0].right_key, c.ops[0].right_leaf, c.ops[0].right_len);
+        c.ops[1].dst_key = nni_batch_keys[2 * t + 1];
+        child(c.n2x, c.ops[1].left_key, c.ops[1].left_leaf, c.ops[1].left_len);
+        child(c.n1b, c.ops[1].right_key, c.ops[1].right_leaf, c.ops[1].right_len);
+        iqhip_branch_task &k = tasks[t];
+        k.ops = c.ops;
+        k.nops = 2;
+        k.max_steps = NNI_MAX_NR_STEP;
+        k.a = iqhip_branch_end{nni_batch_keys[2 * t], -1, 0};
+        k.b = iqhip_branch_end{nni_batch_keys[2 * t + 1], -1, 0};
+        k.xguess = c.node1->findNeighbor(c.node2)->length;
+        k.x1 = min_branch_length;
+        k.x2 = max_branch_length;
+        k.xacc = min_branch_length;
+    }
+    // the tasks hold pointers into cands: do not touch cands from here on.
+    // Two rounds: the reference evaluates the second swap of a branch starting from the length the first swap's
+    // optimisation left on that branch (the Neighbor copies are restored only after both, phylotree.cpp:3036-3051),
+    // so the first swaps of all branches run side by side, then the second swaps with those lengths as guesses.
+    std::vector<double> sum_scale(2 * cands.size(), 0.0);
+    std::vector<iqhip_branch_result> res(cands.size());
+    for (int round = 0; round < 2; round++) {
+        std::vector<iqhip_branch_task> sub;
+        for (size_t t = round; t < tasks.size(); t += 2) {
+            if (round == 1) tasks[t].xguess = res[t - 1].optx;
+            sub.push_back(tasks[t]);
+        }
+        std::vector<double> ss(2 * sub.size(), 0.0);
+        std::vector<iqhip_branch_result> rr(sub.size());
+        check(iqhip_optimize_branch_batch(engine, sub.data(), (int)sub.size(), ss.data(), rr.data()),
+              "iqhip_optimize_branch_batch");
+        num_submissions++;
+        for (size_t q = 0; q < sub.size(); q++) {
+            const size_t t = 2 * q + round;
+            res[t] = rr[q];
+            sum_scale[2 * t] = ss[2 * q];
+            sum_scale[2 * t + 1] = ss[2 * q + 1];
+        }
+    }
+    moves.assign(cands.size(), NNIMove());
+    for (size_t t = 0; t < cands.size(); t++) {
+        const Cand &c = cands[t];
+        NNIMove &m = moves[t];
+        m.node1 = c.node1->id;
+        m.node2 = c.node2->id;
+        m.node1_nei = c.n1a->node->id;
+        m.node2_nei = c.n2x->node->id;
+        m.newLen[0] = res[t].optx;
+        num_derv_calls += res[t].nsteps;
+        if (res[t].status == 2) throw std::runtime_error("Wrong computeFuncDerv (non-finite derivative)");
+        const double sf = c.n1a->lh_scale_factor + c.n2o->lh_scale_factor + sum_scale[2 * t] +
+                          c.n2x->lh_scale_factor + c.n1b->lh_scale_factor + sum_scale[2 * t + 1];
+        m.newloglh = res[t].lnl + sf;
+        if (res[t].optx > max_branch_length * 0.95) {
+            // diverged Newton (phylotree.cpp:2167-2176): rare; take the one-branch path for this candidate
+            NNIMove two[2];
+            getBestNNIForBran(c.node1, c.node2, false, two);
+            m = two[t & 1];
+        }
+    }
+}
+
 // =========================================================================================
 // host views
 // =========================================================================================

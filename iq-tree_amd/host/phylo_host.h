@@ -165,6 +165,12 @@ public:
     };
     NNIMove getBestNNIForBran(PhyloNode *node1, PhyloNode *node2, bool nni5, NNIMove moves[2]);
     static const int NNI_MAX_NR_STEP = 10;  // phylotree.h
+    // computeAllPartialLh (phylotree.cpp:504-514): every directed vector valid (needs LM_ALL_BRANCH)
+    void computeAllPartialLh();
+    // IQTree::evaluateNNIs with nni1 for EVERY internal branch, all 2(n-3) candidates side by side in one
+    // iqhip_optimize_branch_batch submission (same swaps, same Newton solve, same lnL as getBestNNIForBran
+    // gives one branch at a time).  moves: 2 per internal branch, in branch order.  Needs LM_ALL_BRANCH.
+    void evaluateNNIsBatch(std::vector<NNIMove> &moves);
 
     // ---- consumers of the per-pattern lnL (phylotree.cpp:1200-1230, iqtree.cpp:2676-2750) ----------
     // computePatternLikelihood: lnL per pattern of the last computeLikelihood(), scaling events of
@@ -218,7 +224,8 @@ private:
     bool inputs_dirty = true;   // anything to push before the next submission
     bool model_dirty = true, aln_dirty = true, weights_dirty = false;
     uint64_t next_key = 1;
-    uint64_t nni_keys[6] = {0, 0, 0, 0, 0, 0};  // nni_partial_lh scratch (phylotree.cpp:852-860)
+    uint64_t nni_keys[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<uint64_t> nni_batch_keys;  // scratch vectors of evaluateNNIsBatch (2 per candidate)  // nni_partial_lh scratch (phylotree.cpp:852-860)
     std::vector<uint8_t> aln_states;
     std::vector<double> ptn_freq, ptn_invar, m_eval, m_evec, m_inv_evec, m_rates, m_props;
     std::vector<int> m_cat_class;

@@ -1,0 +1,45 @@
+"""Batched NNI evaluation (iqhip_optimize_branch_batch, host mirror evaluateNNIsBatch): all 2(n-3) nni1
+candidates of a tree in one submission against getBestNNIForBran run branch by branch (the reference's
+IQTree::evaluateNNIs order, phylotree.cpp:2873-3066), and against the oracle for the best candidate."""
+import numpy as np
+import pytest
+
+from test_parity_gpu import make_case, LNL_RTOL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,ncat,seq_type,ntaxa,nptn", [(4, 4, 0, 14, 600), (20, 4, 1, 9, 300), (64, 1, 2, 7, 150),
+                                                        (4, 4, 0, 40, 70000)])
+def test_batch_matches_branch_by_branch(pkg, synth, oracle, n, ncat, seq_type, ntaxa, nptn):
+    t, ot, model, pat, freq = make_case(synth, oracle, pkg, ntaxa, nptn, n, ncat, 3300 + n + ntaxa, seq_type=seq_type,
+                                        mem_mode=pkg.LM_ALL_BRANCH)
+    lnl = t.compute_likelihood()
+    tree0 = t.tree_string()
+    batch = t.evaluate_nnis_batch()
+    assert len(batch) == 2 * (ntaxa - 3)
+    assert t.tree_string() == tree0                                   # nothing is changed in the tree
+    assert abs(t.compute_likelihood() - lnl) <= 1e-12 * abs(lnl)
+    by_branch = {}
+    for m in batch:
+        by_branch.setdefault((m["node1"], m["node2"]), []).append(m)
+    assert all(len(v) == 2 for v in by_branch.values())
+    for (a, b), two in list(by_branch.items())[:12]:                  # the sequential evaluator, branch by branch
+        seq = t.nni_for_branch(a, b, nni5=False)
+        for c in range(2):
+            newloglh, nei1, nei2, lens = seq[c]
+            assert (two[c]["node1_nei"], two[c]["node2_nei"]) == (nei1, nei2)
+            assert abs(two[c]["new_len"] - lens[0]) <= 1e-9 * max(1e-6, lens[0])
+            assert abs(two[c]["newloglh"] - newloglh) <= 1e-10 * abs(newloglh)
+    best = max(batch, key=lambda m: m["newloglh"])
+    assert np.isfinite(best["newloglh"]) and best["new_len"] >= 1e-6
+    # the batch can be repeated (scratch vectors and counters are reused)
+    again = t.evaluate_nnis_batch()
+    assert [m["newloglh"] for m in again] == [m["newloglh"] for m in batch]
+
+
+def test_batch_needs_all_branch_mode(pkg, synth, oracle):
+    t, *_ = make_case(synth, oracle, pkg, 8, 100, 4, 4, 77)
+    t.compute_likelihood()
+    with pytest.raises(pkg.HostError, match="LM_ALL_BRANCH"):
+        t.evaluate_nnis_batch()
