@@ -178,6 +178,7 @@ def libiqhost():
     lib.iqhost_nni_for_branch.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
     lib.iqhost_evaluate_nnis_batch.argtypes = [vp, C.POINTER(C.c_int), dp, C.c_int, C.POINTER(C.c_int)]
     lib.iqhost_compute_all_partial_lh.argtypes = [vp]
+    lib.iqhost_evaluate_nnis5_batch.argtypes = [vp, C.POINTER(C.c_int), dp, C.c_int, C.POINTER(C.c_int)]
     lib.iqhost_tree_string.argtypes = [vp, C.c_char_p, C.c_int]
     lib.iqhost_fetch_scale_num.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int16)]
     lib.iqhost_fetch_partial.argtypes = [vp, C.c_int, C.c_int, dp]
@@ -460,6 +461,18 @@ class PhyloTree:
         return [dict(node1=int(ids[4 * k]), node2=int(ids[4 * k + 1]), node1_nei=int(ids[4 * k + 2]),
                      node2_nei=int(ids[4 * k + 3]), new_len=float(vals[2 * k]), newloglh=float(vals[2 * k + 1]))
                 for k in range(n.value)]
+
+    def evaluate_nnis5_batch(self):
+        """all nni5 candidates in ten submissions -> list of dict(node1, node2, node1_nei, node2_nei, new_lens[5], newloglh)"""
+        cap = 4 * self.num_nodes
+        ids = np.zeros(4 * cap, dtype=np.int32)
+        vals = np.zeros(6 * cap)
+        n = C.c_int()
+        self._chk(self.lib.iqhost_evaluate_nnis5_batch(self.h, ids.ctypes.data_as(C.POINTER(C.c_int)), _dptr(vals), cap,
+                                                       C.byref(n)))
+        return [dict(node1=int(ids[4 * k]), node2=int(ids[4 * k + 1]), node1_nei=int(ids[4 * k + 2]),
+                     node2_nei=int(ids[4 * k + 3]), new_lens=[float(x) for x in vals[6 * k:6 * k + 5]],
+                     newloglh=float(vals[6 * k + 5])) for k in range(n.value)]
 
     def compute_all_partial_lh(self):
         self._chk(self.lib.iqhost_compute_all_partial_lh(self.h))

@@ -251,6 +251,21 @@ int iqhost_evaluate_nnis_batch(void *h, int *ids, double *vals, int cap, int *n)
         }
     });
 }
+// nni5 batch: vals[6*k + {0..5}] = newLen[0..4], newloglh
+int iqhost_evaluate_nnis5_batch(void *h, int *ids, double *vals, int cap, int *n) {
+    IQHOST_TRY({
+        std::vector<PhyloTree::NNIMove> mv;
+        ((PhyloTree *)h)->evaluateNNIs5Batch(mv);
+        if ((int)mv.size() > cap) throw std::runtime_error("output too small");
+        *n = (int)mv.size();
+        for (size_t k = 0; k < mv.size(); k++) {
+            ids[4 * k] = mv[k].node1; ids[4 * k + 1] = mv[k].node2;
+            ids[4 * k + 2] = mv[k].node1_nei; ids[4 * k + 3] = mv[k].node2_nei;
+            for (int i = 0; i < 5; i++) vals[6 * k + i] = mv[k].newLen[i];
+            vals[6 * k + 5] = mv[k].newloglh;
+        }
+    });
+}
 int iqhost_compute_all_partial_lh(void *h) { IQHOST_TRY(((PhyloTree *)h)->computeAllPartialLh()); }
 int iqhost_last_plan(void *h, int *ints, double *lens, uint64_t *keys, int cap) {
     PhyloTree *t = (PhyloTree *)h;

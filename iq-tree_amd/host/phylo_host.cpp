@@ -1039,6 +1039,173 @@ void PhyloTree::evaluateNNIsBatch(std::vector<NNIMove> &moves) {
     }
 }
 
+void PhyloTree::evaluateNNIs5Batch(std::vector<NNIMove> &moves) {
+    if (!engine || dry_run) throw std::runtime_error("evaluateNNIs5Batch needs an attached engine");
+    if (allreduce_hook || n_unobserved > 0) throw std::runtime_error("evaluateNNIs5Batch: sharded / +ASC runs use getBestNNIForBran");
+    computeAllPartialLh();
+    pushInputs();
+    // an outward subtree vector around the branch: fixed while the candidate is evaluated
+    struct Ext { uint64_t key; int32_t leaf; double sf; };
+    auto ext_of = [](PhyloNeighbor *nb) {
+        Ext x;
+        if (nb->node->isLeaf()) { x.key = 0; x.leaf = nb->node->id; x.sf = 0.0; }
+        else { x.key = nb->partial_lh; x.leaf = -1; x.sf = nb->lh_scale_factor; }
+        return x;
+    };
+    struct Branch {  // one internal branch: the five Neighbor lengths carry over from the first swap to the second
+        PhyloNode *node1, *node2;
+        PhyloNeighbor *n1[2], *n2[2];
+        double len1[2], len2[2], l0;
+    };
+    std::vector<Branch> branches;
+    for (PhyloNode *node1 : nodes)
+        for (PhyloNeighbor *nb12 : node1->neighbors) {
+            PhyloNode *node2 = nb12->node;
+            if (node1->isLeaf() || node2->isLeaf() || node1->id > node2->id) continue;
+            if (node1->degree() != 3 || node2->degree() != 3) throw std::runtime_error("evaluateNNIs5Batch needs a binary tree");
+            Branch b;
+            b.node1 = node1; b.node2 = node2;
+            int i = 0, j = 0;
+            for (PhyloNeighbor *nb : node1->neighbors) if (nb->node != node2) { b.n1[i] = nb; b.len1[i++] = nb->length; }
+            for (PhyloNeighbor *nb : node2->neighbors) if (nb->node != node1) { b.n2[j] = nb; b.len2[j++] = nb->length; }
+            b.l0 = nb12->length;
+            branches.push_back(b);
+        }
+    const size_t nb = branches.size();
+    while (nni_batch_keys.size() < 4 * nb) nni_batch_keys.push_back(next_key++);
+    moves.assign(2 * nb, NNIMove());
+    struct Work {
+        Ext X[2], Y[2];           // subtrees at node1 (X1 = moved in, X2) and at node2 in optimisation order
+        double lX[2], lY[2], l0;
+        double *outX[2], *outY[2];  // where the optimised lengths go back to (the Branch's Neighbor slots)
+        uint64_t s0, s1, s2, s3;
+        double sf0, sf1, sf2, sf3;
+        iqhip_node_op ops[2];
+        bool diverged;
+    };
+    auto mkop = [](uint64_t dst, const Ext *a, uint64_t akey, double alen, const Ext *b, uint64_t bkey, double blen) {
+        iqhip_node_op o;
+        memset(&o, 0, sizeof o);
+        o.dst_key = dst;
+        o.left_key = a ? a->key : akey;  o.left_leaf = a ? a->leaf : -1;  o.left_len = alen;
+        o.right_key = b ? b->key : bkey; o.right_leaf = b ? b->leaf : -1; o.right_len = blen;
+        return o;
+    };
+    for (int cnt = 0; cnt < 2; cnt++) {
+        std::vector<Work> work(nb);
+        for (size_t q = 0; q < nb; q++) {
+            Branch &b = branches[q];
+            Work &w = work[q];
+            // swap n1[0] <-> n2[cnt]: node1 now holds {n2[cnt], n1[1]}, node2 holds n1[0] at n2[cnt]'s index
+            w.X[0] = ext_of(b.n2[cnt]); w.lX[0] = b.len2[cnt];     w.outX[0] = &b.len2[cnt];
+            w.X[1] = ext_of(b.n1[1]);   w.lX[1] = b.len1[1];       w.outX[1] = &b.len1[1];
+            const int moved_pos = cnt, other = 1 - cnt;  // neighbour-index order at node2 (phylotree.cpp:3008-3016)
+            Ext R = ext_of(b.n1[0]), S = ext_of(b.n2[other]);
+            if (moved_pos < other) { w.Y[0] = R; w.lY[0] = b.len1[0]; w.outY[0] = &b.len1[0]; w.Y[1] = S; w.lY[1] = b.len2[other]; w.outY[1] = &b.len2[other]; }
+            else { w.Y[0] = S; w.lY[0] = b.len2[other]; w.outY[0] = &b.len2[other]; w.Y[1] = R; w.lY[1] = b.len1[0]; w.outY[1] = &b.len1[0]; }
+            w.l0 = b.l0;
+            w.s0 = nni_batch_keys[4 * q]; w.s1 = nni_batch_keys[4 * q + 1];
+            w.s2 = nni_batch_keys[4 * q + 2]; w.s3 = nni_batch_keys[4 * q + 3];
+            w.diverged = false;
+            NNIMove &m = moves[2 * q + cnt];
+            m.node1 = b.node1->id; m.node2 = b.node2->id;
+            m.node1_nei = b.n1[0]->node->id; m.node2_nei = b.n2[cnt]->node->id;
+        }
+        for (int round = 0; round < 5; round++) {
+            std::vector<iqhip_branch_task> tasks(nb);
+            for (size_t q = 0; q < nb; q++) {
+                Work &w = work[q];
+                iqhip_branch_task &k = tasks[q];
+                memset(&k, 0, sizeof k);
+                k.ops = w.ops;
+                k.max_steps = NNI_MAX_NR_STEP;
+                k.x1 = min_branch_length; k.x2 = max_branch_length; k.xacc = min_branch_length;
+                const Ext &Ya = w.Y[0], &Yb = w.Y[1];
+                switch (round) {
+                    case 0:  // branch node1 - X1: u12 = f(Y...), w = f(u12, X2)
+                        w.ops[0] = mkop(w.s0, &Ya, 0, w.lY[0], &Yb, 0, w.lY[1]);
+                        w.ops[1] = mkop(w.s1, nullptr, w.s0, w.l0, &w.X[1], 0, w.lX[1]);
+                        k.nops = 2; k.a = iqhip_branch_end{w.X[0].key, w.X[0].leaf, 0}; k.b = iqhip_branch_end{w.s1, -1, 0};
+                        k.xguess = w.lX[0];
+                        break;
+                    case 1:  // branch node1 - X2
+                        w.ops[0] = mkop(w.s1, nullptr, w.s0, w.l0, &w.X[0], 0, w.lX[0]);
+                        k.nops = 1; k.a = iqhip_branch_end{w.X[1].key, w.X[1].leaf, 0}; k.b = iqhip_branch_end{w.s1, -1, 0};
+                        k.xguess = w.lX[1];
+                        break;
+                    case 2:  // central branch
+                        w.ops[0] = mkop(w.s2, &w.X[0], 0, w.lX[0], &w.X[1], 0, w.lX[1]);
+                        k.nops = 1; k.a = iqhip_branch_end{w.s0, -1, 0}; k.b = iqhip_branch_end{w.s2, -1, 0};
+                        k.xguess = w.l0;
+                        break;
+                    case 3:  // branch node2 - Y1
+                        w.ops[0] = mkop(w.s3, nullptr, w.s2, w.l0, &Yb, 0, w.lY[1]);
+                        k.nops = 1; k.a = iqhip_branch_end{Ya.key, Ya.leaf, 0}; k.b = iqhip_branch_end{w.s3, -1, 0};
+                        k.xguess = w.lY[0];
+                        break;
+                    default:  // branch node2 - Y2
+                        w.ops[0] = mkop(w.s3, nullptr, w.s2, w.l0, &Ya, 0, w.lY[0]);
+                        k.nops = 1; k.a = iqhip_branch_end{Yb.key, Yb.leaf, 0}; k.b = iqhip_branch_end{w.s3, -1, 0};
+                        k.xguess = w.lY[1];
+                        break;
+                }
+            }
+            std::vector<double> ss(2 * nb + 2, 0.0);
+            std::vector<iqhip_branch_result> rr(nb);
+            check(iqhip_optimize_branch_batch(engine, tasks.data(), (int)nb, ss.data(), rr.data()),
+                  "iqhip_optimize_branch_batch");
+            num_submissions++;
+            size_t sp = 0;
+            for (size_t q = 0; q < nb; q++) {
+                Work &w = work[q];
+                const iqhip_branch_result &r = rr[q];
+                if (r.status == 2) throw std::runtime_error("Wrong computeFuncDerv (non-finite derivative)");
+                if (r.optx > max_branch_length * 0.95) w.diverged = true;
+                num_derv_calls += r.nsteps;
+                NNIMove &m = moves[2 * q + cnt];
+                switch (round) {
+                    case 0:
+                        w.sf0 = w.Y[0].sf + w.Y[1].sf + ss[sp];
+                        w.sf1 = w.sf0 + w.X[1].sf + ss[sp + 1];
+                        sp += 2;
+                        w.lX[0] = r.optx; m.newLen[1] = r.optx;
+                        break;
+                    case 1:
+                        w.sf1 = w.sf0 + w.X[0].sf + ss[sp++];
+                        w.lX[1] = r.optx; m.newLen[2] = r.optx;
+                        break;
+                    case 2:
+                        w.sf2 = w.X[0].sf + w.X[1].sf + ss[sp++];
+                        w.l0 = r.optx; m.newLen[0] = r.optx;
+                        break;
+                    case 3:
+                        w.sf3 = w.sf2 + w.Y[1].sf + ss[sp++];
+                        w.lY[0] = r.optx; m.newLen[3] = r.optx;
+                        break;
+                    default:
+                        w.sf3 = w.sf2 + w.Y[0].sf + ss[sp++];
+                        w.lY[1] = r.optx; m.newLen[4] = r.optx;
+                        m.newloglh = r.lnl + w.Y[1].sf + w.sf3;
+                        break;
+                }
+            }
+        }
+        // the lengths the swap left on the five Neighbor objects are the second swap's starting point
+        for (size_t q = 0; q < nb; q++) {
+            Work &w = work[q];
+            *w.outX[0] = w.lX[0]; *w.outX[1] = w.lX[1];
+            *w.outY[0] = w.lY[0]; *w.outY[1] = w.lY[1];
+            branches[q].l0 = w.l0;
+            if (w.diverged) {  // diverged Newton (phylotree.cpp:2167-2176): rare; take the branch-by-branch path
+                NNIMove two[2];
+                getBestNNIForBran(branches[q].node1, branches[q].node2, true, two);
+                moves[2 * q] = two[0];
+                moves[2 * q + 1] = two[1];
+            }
+        }
+    }
+}
+
 // =========================================================================================
 // host views
 // =========================================================================================

@@ -171,6 +171,10 @@ public:
     // iqhip_optimize_branch_batch submission (same swaps, same Newton solve, same lnL as getBestNNIForBran
     // gives one branch at a time).  moves: 2 per internal branch, in branch order.  Needs LM_ALL_BRANCH.
     void evaluateNNIsBatch(std::vector<NNIMove> &moves);
+    // the same with nni5 (the reference's default, params.nni5): per candidate the two branches at node1, the
+    // central branch and the two at node2 are optimised in that order (phylotree.cpp:2984-3024); five rounds of
+    // batched tasks per swap, ten submissions per tree instead of ~10 per branch
+    void evaluateNNIs5Batch(std::vector<NNIMove> &moves);
 
     // ---- consumers of the per-pattern lnL (phylotree.cpp:1200-1230, iqtree.cpp:2676-2750) ----------
     // computePatternLikelihood: lnL per pattern of the last computeLikelihood(), scaling events of

@@ -43,3 +43,33 @@ def test_batch_needs_all_branch_mode(pkg, synth, oracle):
     t.compute_likelihood()
     with pytest.raises(pkg.HostError, match="LM_ALL_BRANCH"):
         t.evaluate_nnis_batch()
+
+
+@pytest.mark.parametrize("n,ncat,seq_type,ntaxa,nptn", [(4, 4, 0, 13, 500), (20, 4, 1, 8, 250), (4, 4, 0, 30, 40000)])
+def test_nni5_batch_matches_branch_by_branch(pkg, synth, oracle, n, ncat, seq_type, ntaxa, nptn):
+    """nni5 (the reference's default): five branches per candidate, optimised in the reference's order; the second
+    swap of a branch starts from the lengths the first swap left."""
+    t, ot, model, pat, freq = make_case(synth, oracle, pkg, ntaxa, nptn, n, ncat, 4400 + n + ntaxa, seq_type=seq_type,
+                                        mem_mode=pkg.LM_ALL_BRANCH)
+    lnl = t.compute_likelihood()
+    tree0 = t.tree_string()
+    batch = t.evaluate_nnis5_batch()
+    assert len(batch) == 2 * (ntaxa - 3) and t.tree_string() == tree0
+    assert abs(t.compute_likelihood() - lnl) <= 1e-12 * abs(lnl)
+    checked = 0
+    for k in range(0, len(batch), 2):
+        a, b = batch[k]["node1"], batch[k]["node2"]
+        seq = t.nni_for_branch(a, b, nni5=True)
+        for c in range(2):
+            newloglh, nei1, nei2, lens = seq[c]
+            m = batch[k + c]
+            assert (m["node1_nei"], m["node2_nei"]) == (nei1, nei2)
+            np.testing.assert_allclose(m["new_lens"], lens, rtol=1e-7, atol=1e-12)
+            assert abs(m["newloglh"] - newloglh) <= 1e-9 * abs(newloglh)
+            checked += 1
+        if checked >= 16:
+            break
+    # the best nni5 candidate is at least as good as the best nni1 candidate evaluated the same way
+    best1 = max(m["newloglh"] for m in t.evaluate_nnis_batch())
+    best5 = max(m["newloglh"] for m in batch)
+    assert best5 >= best1 - 1e-6 * abs(best1)

@@ -20,5 +20,16 @@ for (T, P) in ((44, 355), (50, 5000), (50, 100000)):
     for (x, y) in branches:
         t.nni_for_branch(x, y, nni5=False)
     ts = time.perf_counter() - t0
-    print("taxa %d patterns %d: %d candidates; branch by branch %.2f ms (%.1f us per candidate), batched %.2f ms "
+    print("taxa %d patterns %d: %d candidates; nni1 branch by branch %.2f ms (%.1f us per candidate), batched %.2f ms "
           "(%.1f us per candidate)" % (T, P, len(b), ts * 1e3, ts * 1e6 / len(b), tb * 1e3, tb * 1e6 / len(b)))
+    b5 = t.evaluate_nnis5_batch()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        b5 = t.evaluate_nnis5_batch()
+    tb5 = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for (x, y) in branches:
+        t.nni_for_branch(x, y, nni5=True)
+    ts5 = time.perf_counter() - t0
+    print("    nni5 branch by branch %.2f ms (%.1f us per candidate), batched %.2f ms (%.1f us per candidate)" %
+          (ts5 * 1e3, ts5 * 1e6 / len(b5), tb5 * 1e3, tb5 * 1e6 / len(b5)))
