@@ -932,9 +932,24 @@ PhyloTree::NNIMove PhyloTree::getBestNNIForBran(PhyloNode *node1, PhyloNode *nod
 void PhyloTree::computeAllPartialLh() {
     if (lh_mem_save != LM_ALL_BRANCH) throw std::runtime_error("computeAllPartialLh needs LM_ALL_BRANCH");
     if (!central_partial_lh) initializeAllPartialLh();
+    // one plan for every pending directed vector (each has its own buffer in this mode), one submission
+    std::vector<PlanOp> plan;
     for (PhyloNode *node : nodes)
         for (PhyloNeighbor *nb : node->neighbors)
-            if (!nb->node->isLeaf() && (nb->partial_lh_computed & 1) == 0) computePartialLikelihood(nb, node);
+            if (!nb->node->isLeaf() && (nb->partial_lh_computed & 1) == 0) collectPlan(nb, node, plan);
+    last_plan = plan;
+    if (plan.empty()) return;
+    std::vector<double> sum_scale(plan.size(), 0.0);
+    if (!dry_run) {
+        if (!engine) throw std::runtime_error("HIP likelihood kernel selected but no engine attached");
+        if (allreduce_hook) throw std::runtime_error("computeAllPartialLh: not available on a sharded tree");
+        pushInputs();
+        std::vector<iqhip_node_op> ops(plan.size());
+        for (size_t k = 0; k < plan.size(); k++) ops[k] = plan[k].op;
+        check(iqhip_update_partials(engine, ops.data(), (int)ops.size(), sum_scale.data()), "iqhip_update_partials");
+        num_submissions++;
+    }
+    applyScaleFactors(plan, sum_scale);
 }
 
 void PhyloTree::evaluateNNIsBatch(std::vector<NNIMove> &moves) {

@@ -73,3 +73,21 @@ def test_nni5_batch_matches_branch_by_branch(pkg, synth, oracle, n, ncat, seq_ty
     best1 = max(m["newloglh"] for m in t.evaluate_nnis_batch())
     best5 = max(m["newloglh"] for m in batch)
     assert best5 >= best1 - 1e-6 * abs(best1)
+
+
+def test_compute_all_partial_lh_is_one_submission(pkg, synth, oracle):
+    t, ot, *_ = make_case(synth, oracle, pkg, 25, 300, 4, 4, 5151, mem_mode=pkg.LM_ALL_BRANCH)
+    lnl = t.compute_likelihood()
+    n0 = t.num_submissions
+    t.compute_all_partial_lh()
+    # 3T-6 directed vectors point at internal nodes; the traversal made T-2 of them
+    assert t.num_submissions == n0 + 1 and len(t.last_plan()) == 2 * (25 - 2)
+    from test_parity_gpu import check_all_vectors
+    assert check_all_vectors(t, ot) == 3 * 25 - 6
+    # every directed vector is now valid: any branch gives the same lnL without further node updates
+    n1 = t.num_partial_lh_computations
+    for a in range(t.num_nodes):
+        for b, _ in t.neighbors(a):
+            if a < b:
+                assert abs(t.compute_likelihood_branch(a, b) - lnl) <= LNL_RTOL * abs(lnl)
+    assert t.last_plan() == []
