@@ -227,7 +227,7 @@ def main():
         "roofline": roof,
     }
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the CPU baseline is timed at N = 1 only
         od = entry.load_oracle()
         sample = min(P, 100000 if nst == 4 else (4000 if model.ncat <= 4 else 1000))
         ot = od.OracleTree(nwk, nst, seq_type, pat[:, :sample], freq[:sample], None, model)
