@@ -277,3 +277,20 @@ def test_reference_protein_file(pkg):
     assert aln.seq_names[0] == "Acrasis_rosea"
     f = aln.state_freq()
     assert abs(f.sum() - 1) < 1e-12 and f.min() >= 1e-4
+
+
+def test_reader_line_endings_case_and_strict_names(pkg):
+    crlf = " 3 6\r\nalpha  acgtac\r\nbeta   ACGTAC\r\ngamma  ACG-AC\r\n"
+    a = pkg.Alignment(content=crlf)
+    assert a.seq_names == ["alpha", "beta", "gamma"] and a.nsite == 6 and a.npattern == 4
+    # no blank in the line: the first 10 characters are the name (strict PHYLIP, alignment.cpp:1421-1424)
+    strict = " 3 4\nsequence_1ACGT\nsequence_2ACGA\nsequence_3ACGC\n"
+    b = pkg.Alignment(content=strict)
+    assert b.seq_names == ["sequence_1", "sequence_2", "sequence_3"] and b.nsite == 4
+    # protein detection, '*' and 'U' are unknown, FASTA names stop at the first blank
+    f = pkg.Alignment(content=">s1 some description\nMKV*LU\n>s2\nMKVALX\n>s3\nMRVAL-\n")
+    assert f.seq_type == pkg.SEQ_PROTEIN and f.seq_names == ["s1", "s2", "s3"]
+    st, _, sp, _ = f.arrays()
+    assert st[:, sp][0].tolist()[3] == 23 and st[:, sp][0].tolist()[5] == 23 and st[:, sp][2].tolist()[5] == 23
+    with pytest.raises(pkg.HostError, match="Unknown sequence type|Invalid"):
+        pkg.Alignment(content=" 3 4\na 0123\nb 0123\nc 0123\n")
