@@ -233,7 +233,10 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
 // Host canonical form as for DNA: left in {LEAF, PF}, right in {LEAF, PREV}; (PF, LOAD) reads the
 // right child synchronously into the `prev` registers.
 // ---------------------------------------------------------------------------------------
-template <int N, int C, int WG>
+// CS > 1 (category split): the CS waves of a workgroup share ONE tile and own C = ncat/CS categories each, so a
+// small alignment yields CS times the waves with 1/CS of the dependent MFMA chain per op; the only cross-wave step is
+// the scaling maximum of a pattern (LDS + one workgroup barrier per op).
+template <int N, int C, int WG, int CS = 1>
 __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
     // rows of U / U^-1: MTF full 16-row tiles on v_mfma_f64_16x16x4_f64 plus, for N = 20, the four
     // left-over rows on v_mfma_f64_4x4x4_4b_f64 (4 blocks = the tile's 4 groups of 4 patterns).
@@ -246,7 +249,8 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
     static_assert(N % 16 == 0 || TAIL4, "N must be 16m or 16m+4");
     constexpr int KS = N / 4;
     constexpr int WPB = WG / 64;
-    constexpr int B = C * N;
+    constexpr int CT = C * CS;   // categories of the block
+    constexpr int B = CT * N;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *sU = smem;                           // [MTF][KS][64]
     double *sUi = sU + MTF * KS * 64;            // [MTF][KS][64]
@@ -282,7 +286,9 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seg = (int)blockIdx.x / A.ngroups;  // scalar
     const int k_begin = as_const(A.segs)[2 * seg], k_end = k_begin + as_const(A.segs)[2 * seg + 1];
-    const int64_t tile = (int64_t)((int)blockIdx.x - seg * A.ngroups) * WPB + wave;
+    const int64_t tile = (int64_t)((int)blockIdx.x - seg * A.ngroups) * (WPB / CS) + wave / CS;
+    const int coff = (wave % CS) * C;          // first category of this wave
+    const bool lead = (wave % CS) == 0;        // the wave that owns the tile's counters and sums
     const bool active = tile < A.ntiles;
     const int64_t tl = active ? tile : 0;
     const int p = lane & 15, g = lane >> 4;
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
     int pfn_sc = 0;
     {   // prime: streamed child of (first op, category 0); the op after the last one is a sentinel
         const CONST_AS DevOp &f = ops[k_begin];
-        const double *src = f.pf + ((f.real_mask & 1) ? tbase : 0);
+        const double *src = f.pf + ((f.real_mask & 1) ? tbase + (size_t)coff * N * 16 : 0);
 #pragma unroll
         for (int s = 0; s < KS; s++) PFn[s] = src[s * 64 + lane];
         if (g == 0) pfn_sc = f.pf_sc[(f.real_mask & 1) ? ptn : (int64_t)p];
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
                 for (int c = 0; c < C; c++)
 #pragma unroll
                     for (int s = 0; s < KS; s++) {
-                        const double v = src[(size_t)c * N * 16 + s * 64 + lane];
+                        const double v = src[(size_t)(coff + c) * N * 16 + s * 64 + lane];
                         if (s < 4 * MTF) prev[c][s >> 2][s & 3] = v; else prevT[c] = v;
                     }
                 if (g == 0) prev_sc = op.ld_sc[ptn];
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
                 // PFn registers one by one, right after this step has consumed them
                 const CONST_AS DevOp &nd = (c + 1 < C) ? op : nxop;
                 const bool nreal = nd.real_mask & 1;
-                const double *nsrc = nd.pf + (nreal ? tbase + (size_t)((c + 1 < C) ? c + 1 : 0) * N * 16 : 0);
+                const double *nsrc = nd.pf + (nreal ? tbase + (size_t)(coff + ((c + 1 < C) ? c + 1 : 0)) * N * 16 : 0);
                 // N = 20 (5 k-steps): cheaper to copy the operands out and issue the whole prefetch up
                 // front; N = 64 (16 k-steps): stream it, the copies would not fit the register file.
                 // Measured on one box: protein 1.51 ms (copy) vs 1.63 ms (stream); codon 0.708 vs 0.678.
@@ -401,8 +407,8 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
                         vl = bl[s];
                         vr = br[s];
                     }
-                    const double xl = vl * exL[c * N + i];
-                    const double xr = vr * exR[c * N + i];
+                    const double xl = vl * exL[(coff + c) * N + i];
+                    const double xr = vr * exR[(coff + c) * N + i];
 #pragma unroll
                     for (int m = 0; m < MTF; m++) {
                         const double a = sU[aidx<KS>(m, s, lane)];
@@ -456,7 +462,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
                     for (int r = 0; r < 4; r++) {
                         const int row = 16 * m + 4 * r + g;
 #ifndef IQHIP_MFMA_ABLATE_NOSTORE  // timing-only build switch; never defined in the shipped library
-                        dst[(size_t)(c * N + row) * 16 + p] = O[m][r];
+                        dst[(size_t)((coff + c) * N + row) * 16 + p] = O[m][r];
 #endif
                         lmax = fmax(lmax, fabs(O[m][r]));
                     }
@@ -464,13 +470,22 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
                 if (TAIL4) {
                     prevT[c] = o4;
 #ifndef IQHIP_MFMA_ABLATE_NOSTORE
-                    dst[(size_t)(c * N + 16 * MTF + g) * 16 + p] = o4;
+                    dst[(size_t)((coff + c) * N + 16 * MTF + g) * 16 + p] = o4;
 #endif
                     lmax = fmax(lmax, fabs(o4));
                 }
             }
             lmax = fmax(lmax, __shfl_xor(lmax, 16, 64));
             lmax = fmax(lmax, __shfl_xor(lmax, 32, 64));
+            if constexpr (CS > 1) {  // maximum over the categories held by the other waves of this tile
+                __shared__ double s_lmax[2][WG / 64][16];
+                const int par = k & 1;
+                if (g == 0) s_lmax[par][wave][p] = lmax;
+                __syncthreads();
+                const int w0 = (wave / CS) * CS;
+#pragma unroll
+                for (int q = 0; q < CS; q++) lmax = fmax(lmax, s_lmax[par][w0 + q][p]);
+            }
             const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0);
             double my_scale = 0.0;
             if (__any(do_scale)) {
@@ -482,21 +497,21 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
 #pragma unroll
                             for (int r = 0; r < 4; r++) {
                                 prev[c][m][r] *= kScalingThresholdInv;
-                                dst[(size_t)(c * N + 16 * m + 4 * r + g) * 16 + p] = prev[c][m][r];
+                                dst[(size_t)((coff + c) * N + 16 * m + 4 * r + g) * 16 + p] = prev[c][m][r];
                             }
                         if (TAIL4) {
                             prevT[c] *= kScalingThresholdInv;
-                            dst[(size_t)(c * N + 16 * MTF + g) * 16 + p] = prevT[c];
+                            dst[(size_t)((coff + c) * N + 16 * MTF + g) * 16 + p] = prevT[c];
                         }
                     }
                     sc += 1;
-                    if (g == 0 && ptn < A.nptn) my_scale = kLogScalingThreshold * freq;
+                    if (lead && g == 0 && ptn < A.nptn) my_scale = kLogScalingThreshold * freq;
                 }
             }
             prev_sc = sc;
-            if (g == 0) op.dst_sc[ptn] = (int16_t)sc;
+            if (lead && g == 0) op.dst_sc[ptn] = (int16_t)sc;
             const double ws = wave_sum_m(my_scale);
-            if (lane == 0) A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
+            if (lead && lane == 0) A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
         }
     }
 }
@@ -675,20 +690,21 @@ int mfma2_fixed_lds_doubles(int n) {
     return 2 * mtf * ks * 64 + ((n % 16) == 4 ? 2 * ks * 64 : 0) + (n * n * 8 <= 4096 ? n * n : 0);
 }
 
-template <int N, int C>
+template <int N, int C, int CS = 1>
 static hipError_t launch_trav_m2(iqhip_engine *e, TravMArgs &A) {
     constexpr int KS = N / 4, WG = 256;
     const int nx = e->state_unknown + 1 - N;
     const size_t lds = (size_t)(mfma2_fixed_lds_doubles(N) + nx * N + e->plan_lds_doubles) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma2<N, C, WG>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma2<N, C, WG, CS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    A.ngroups = (int)((A.ntiles + 3) / 4);
+    A.ngroups = (int)((A.ntiles * CS + 3) / 4);
     const int grid = A.ngroups * A.nsegs_launch;
-    hipLaunchKernelGGL((k_traverse_mfma2<N, C, WG>), dim3(grid), dim3(WG), lds, e->stream, A);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((k_traverse_mfma2<N, C, WG, CS>), dim3(grid), dim3(WG), lds, e->stream, A);
     return hipGetLastError();
 }
 
@@ -717,7 +733,7 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs
     A.state_unknown = e->state_unknown;
     if (nsegs <= 0) return hipSuccess;
     if (e->mfma_pipelined) {  // plan was built in canonical (PF, PREV) form
-        if (e->n == 20 && e->ncat == 4) return launch_trav_m2<20, 4>(e, A);
+        if (e->n == 20 && e->ncat == 4) return e->cat_split ? launch_trav_m2<20, 1, 4>(e, A) : launch_trav_m2<20, 4>(e, A);
         if (e->n == 20 && e->ncat == 1) return launch_trav_m2<20, 1>(e, A);
         if (e->n == 64 && e->ncat == 1) return launch_trav_m2<64, 1>(e, A);
         return hipErrorInvalidValue;

@@ -749,3 +749,23 @@ def test_invariant_site_proportion_changes_on_an_attached_engine(pkg, synth, ora
     ot.freq = np.ascontiguousarray(f2, dtype=np.float64)
     ot.clear()
     assert abs(t.compute_likelihood_branch(a, b) - ot.branch_lnl(a, b)[0]) <= LNL_RTOL * abs(ref2)
+
+
+@pytest.mark.parametrize("ntaxa,kw", [(20, dict(missing=0.04)), (120, dict(lo=0.3, hi=0.7, caterpillar=True))])
+def test_category_split_gives_identical_vectors(pkg, synth, oracle, ntaxa, kw, monkeypatch):
+    """20-state kernel, one wave per category of a tile (small alignments) against one wave per tile: identical
+    vectors and counters (the per-category arithmetic is the same; the scaling maximum crosses waves through LDS)."""
+    out = []
+    for cs in ("0", "1"):
+        monkeypatch.setenv("IQHIP_CAT_SPLIT", cs)
+        t, ot, *_ = make_case(synth, oracle, pkg, ntaxa, 200, 20, 4, 6100 + ntaxa, seq_type=1, **kw)
+        lnl = t.compute_likelihood()
+        a, b = t.current_branch()
+        out.append((lnl, t.fetch_partial(a, b), t.fetch_scale_num(a, b), t.neighbor_info(a, b)["lh_scale_factor"]))
+        ref, _ = ot.likelihood()
+        assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+        assert check_all_vectors(t, ot) == ntaxa - 2
+    x, y = out
+    assert x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]) and x[3] == y[3]
+    if "caterpillar" in kw:
+        assert x[2].max() >= 1
