@@ -541,7 +541,9 @@ static hipError_t launch_trav_m(iqhip_engine *e, TravMArgs &A) {
 // multiplied.  The A fragments (U, U^-1 of the component's class: 16-row tile + 4-row tail, 20 doubles)
 // are re-read from the per-class images only when the class changes (block order [class][rate]).
 // ---------------------------------------------------------------------------------------
-template <int WG>
+// CS > 1: the CS waves of a workgroup share one tile and split its components (C % CS == 0), as k_traverse_mfma2's
+// category split does; the scaling maximum crosses the waves through LDS.
+template <int WG, int CS>
 __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_mix20(const TravMArgs A) {
     constexpr int N = 20, KS = 5, WPB = WG / 64;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -552,7 +554,9 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_mix20(const TravMArgs A
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seg = (int)blockIdx.x / A.ngroups;  // scalar
     const int k_begin = as_const(A.segs)[2 * seg], k_end = k_begin + as_const(A.segs)[2 * seg + 1];
-    const int64_t tile = (int64_t)((int)blockIdx.x - seg * A.ngroups) * WPB + wave;
+    const int64_t tile = (int64_t)((int)blockIdx.x - seg * A.ngroups) * (WPB / CS) + wave / CS;
+    const int c_lo = (wave % CS) * (C / CS), c_hi = c_lo + C / CS;  // this wave's components
+    const bool lead = (wave % CS) == 0;
     const bool active = tile < A.ntiles;
     const int64_t tl = active ? tile : 0;
     const int p = lane & 15, g = lane >> 4;
@@ -596,13 +600,13 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_mix20(const TravMArgs A
             double lmax = 0.0;
             double nl[KS], nr[KS];
 #pragma unroll
-            for (int s = 0; s < KS; s++) { nl[s] = srcL[s * stepL]; nr[s] = srcR[s * stepR]; }
-            for (int c = 0; c < C; c++) {
+            for (int s = 0; s < KS; s++) { nl[s] = srcL[(size_t)c_lo * strideL + s * stepL]; nr[s] = srcR[(size_t)c_lo * strideR + s * stepR]; }
+            for (int c = c_lo; c < c_hi; c++) {
                 double bl[KS], br[KS];
 #pragma unroll
                 for (int s = 0; s < KS; s++) { bl[s] = nl[s]; br[s] = nr[s]; }
                 {   // request component c+1 (the last request of an op re-reads component C-1: harmless)
-                    const int cn = (c + 1 < C) ? c + 1 : c;
+                    const int cn = (c + 1 < c_hi) ? c + 1 : c;
 #pragma unroll
                     for (int s = 0; s < KS; s++) {
                         nl[s] = srcL[(size_t)cn * strideL + s * stepL];
@@ -654,34 +658,52 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_mix20(const TravMArgs A
             }
             lmax = fmax(lmax, __shfl_xor(lmax, 16, 64));
             lmax = fmax(lmax, __shfl_xor(lmax, 32, 64));
+            if constexpr (CS > 1) {
+                __shared__ double s_lmax[2][WG / 64][16];
+                const int par = k & 1;
+                if (g == 0) s_lmax[par][wave][p] = lmax;
+                __syncthreads();
+                const int w0 = (wave / CS) * CS;
+#pragma unroll
+                for (int q = 0; q < CS; q++) lmax = fmax(lmax, s_lmax[par][w0 + q][p]);
+            }
             const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0);
             double my_scale = 0.0;
             if (__any(do_scale)) {
                 if (do_scale) {
-                    for (int e = g; e < B; e += 4) dst[(size_t)e * 16 + p] *= kScalingThresholdInv;
+                    for (int e = c_lo * N + g; e < c_hi * N; e += 4) dst[(size_t)e * 16 + p] *= kScalingThresholdInv;
                     sc += 1;
-                    if (g == 0 && ptn < A.nptn) my_scale = kLogScalingThreshold * freq;
+                    if (lead && g == 0 && ptn < A.nptn) my_scale = kLogScalingThreshold * freq;
                 }
             }
-            if (g == 0) op.dst_sc[ptn] = (int16_t)sc;
+            if (lead && g == 0) op.dst_sc[ptn] = (int16_t)sc;
             const double ws = wave_sum_m(my_scale);
-            if (lane == 0) A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
+            if (lead && lane == 0) A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
         }
     }
 }
 
-static hipError_t launch_trav_mix20(iqhip_engine *e, TravMArgs &A) {
+template <int CS>
+static hipError_t launch_trav_mix20_cs(iqhip_engine *e, TravMArgs &A) {
     constexpr int WG = 256;
     const size_t lds = (size_t)e->plan_lds_doubles * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma_mix20<WG>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma_mix20<WG, CS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    A.ngroups = (int)((A.ntiles + 3) / 4);
-    hipLaunchKernelGGL((k_traverse_mfma_mix20<WG>), dim3((unsigned)(A.ngroups * A.nsegs_launch)), dim3(WG), lds, e->stream, A);
+    A.ngroups = (int)((A.ntiles * CS + 3) / 4);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((k_traverse_mfma_mix20<WG, CS>), dim3((unsigned)(A.ngroups * A.nsegs_launch)), dim3(WG), lds, e->stream, A);
     return hipGetLastError();
+}
+
+static hipError_t launch_trav_mix20(iqhip_engine *e, TravMArgs &A) {
+    // component split while the alignment is small (fewer than two tiles per SIMD) and the components divide by 4
+    bool split = (e->ncat % 4 == 0) && e->ntiles < 2 * (int64_t)e->num_cus * 4;
+    if (const char *cs = getenv("IQHIP_CAT_SPLIT")) split = (atoi(cs) != 0) && (e->ncat % 4 == 0);
+    return split ? launch_trav_mix20_cs<4>(e, A) : launch_trav_mix20_cs<1>(e, A);
 }
 
 // LDS doubles of k_traverse_mfma2 that do not depend on the plan (A images, tail images, U^-1 transposed)
