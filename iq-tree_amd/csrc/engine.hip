@@ -140,6 +140,10 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
         e->cat_split = 4 * e->ntiles <= (int64_t)e->num_cus * 4;
         if (const char *cs = getenv("IQHIP_CAT_SPLIT")) e->cat_split = atoi(cs) != 0;
     }
+    if (e->mfma_pipelined_ok && e->n == 64 && e->ncat == 1) {
+        e->row_split = 4 * e->ntiles <= (int64_t)e->num_cus * 4;
+        if (const char *rs = getenv("IQHIP_ROW_SPLIT")) e->row_split = atoi(rs) != 0;
+    }
     e->d_result = e->d_result_own;
     hipMemsetAsync(e->d_theta, 0, P * e->block * sizeof(double), e->stream);
     hipMemsetAsync(e->d_pattern_lh, 0, P * sizeof(double), e->stream);
@@ -746,8 +750,9 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         int budget;
         if (e->mfma) {
             const int MT = (e->n + 15) / 16, KS = e->n / 4;
-            const int fixed = (e->mfma_pipelined ? mfma2_fixed_lds_doubles(e->n) : 2 * MT * KS * 64) +
-                              (e->state_unknown + 1 - e->n) * e->n;
+            const int fixed = (e->row_split && e->mfma_pipelined) ? (e->state_unknown + 1) * e->n + 4 * 16 * 64 + 128
+                              : (e->mfma_pipelined ? mfma2_fixed_lds_doubles(e->n) : 2 * MT * KS * 64) +
+                                    (e->state_unknown + 1 - e->n) * e->n;
             // two workgroups per CU (160 KB LDS): <= 78 KB each, images included (a third workgroup
             // for the 20-state kernel was measured: no gain, more chunks); IQHIP_MFMA_LDS_KB overrides
             int total_kb = 78;

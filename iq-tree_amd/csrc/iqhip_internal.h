@@ -82,6 +82,7 @@ struct iqhip_engine {
     bool mfma = false;     // nstates 20 / 64: matrix-core path (kernels_mfma.hip)
     bool mfma_pipelined = false;  // (n, ncat) has a k_traverse_mfma2 instantiation (IQHIP_MFMA_V1=1 disables)
     int wg_size = 256;     // threads per workgroup of the traversal kernel (IQHIP_WG env)
+    bool row_split = false; // 64 states, 1 category: one wave per 16 output rows of a tile (small alignments)
     bool cat_split = false; // 20 states, 4 categories: one wave per category of a tile (small alignments)
     int lane_split = 1;    // 4-state traversal: lanes per pattern (2: each lane owns half of the categories)
     int ablate = 0;        // IQHIP_ABLATE: timing-only host-side switches (results wrong when set)

@@ -706,6 +706,176 @@ static hipError_t launch_trav_mix20(iqhip_engine *e, TravMArgs &A) {
     return split ? launch_trav_mix20_cs<4>(e, A) : launch_trav_mix20_cs<1>(e, A);
 }
 
+// ---------------------------------------------------------------------------------------
+// 64 states, small alignments: ROW SPLIT.  The four waves of a workgroup share one tile; wave w owns the output
+// rows [16w, 16w+16) of every product (one M-tile), i.e. 48 instead of 192 dependent MFMAs per op.  Its 2 x 16 A
+// fragments (U and U^-1 rows) live in registers.  What the other waves need of a result -- the Hadamard product
+// T before the U^-1 contraction, and the previous result when it is the next op's operand -- is exchanged through
+// LDS as B-operand k-step slices (the accumulator image of M-tile w IS k-steps 4w..4w+3), one workgroup barrier
+// each; the scaling maximum takes a third.  Same canonical plan form as k_traverse_mfma2 (C = 1).
+// ---------------------------------------------------------------------------------------
+template <int WG>
+__global__ __launch_bounds__(WG, 2) void k_traverse_mfma_rows64(const TravMArgs A) {
+    constexpr int N = 64, KS = 16, B = 64;
+    static_assert(WG == 256, "one tile per workgroup of four waves");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int nx = A.state_unknown + 1 - N;
+    double *sTip = smem;                       // [N + nx][N] tip_partial_lh rows
+    double *sX = sTip + (N + nx) * N;          // [2 parities][KS][64] previous result as k-step slices
+    double *sT = sX + 2 * KS * 64;             // [2 parities][KS][64] Hadamard product
+    double *sReg = sT + 2 * KS * 64;           // per (op, child) exponentials [N] of the chunk
+    __shared__ double s_lmax[2][4][16];
+    for (int t = threadIdx.x; t < (N + nx) * N; t += WG) sTip[t] = A.tip[t];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int seg = (int)blockIdx.x / A.ngroups;  // scalar
+    const int k_begin = as_const(A.segs)[2 * seg], k_end = k_begin + as_const(A.segs)[2 * seg + 1];
+    const int64_t tile = (int64_t)((int)blockIdx.x - seg * A.ngroups);
+    const bool active = tile < A.ntiles;          // uniform over the workgroup
+    const int64_t tl = active ? tile : 0;
+    const int p = lane & 15, g = lane >> 4;
+    const int64_t ptn = tl * 16 + p;
+    const size_t tbase = (size_t)tl * 16 * B;
+    const double freq = A.freq[ptn];
+    const double invar = A.invar[ptn];
+    const CONST_AS DevOp *ops = as_const(A.ops);
+    const bool lead = wave == 0;
+
+    // A fragments of this wave's 16 rows: lane (row = 16*wave + (lane & 15), k = 4s + (lane >> 4))
+    double aU[KS], aUi[KS];
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+        const int row = 16 * wave + (lane & 15), kk = 4 * s + (lane >> 4);
+        aU[s] = A.evec[row * N + kk];
+        aUi[s] = A.inv_evec[row * N + kk];
+    }
+    v4f64 prev = {0, 0, 0, 0};   // rows 16*wave + 4r + g of the previous result
+    int prev_sc = 0;
+    double PFn[KS];
+    int pfn_sc = 0;
+    {
+        const CONST_AS DevOp &f = ops[k_begin];
+        const double *src = f.pf + ((f.real_mask & 1) ? tbase : 0);
+#pragma unroll
+        for (int s = 0; s < KS; s++) PFn[s] = src[s * 64 + lane];
+        if (g == 0) pfn_sc = f.pf_sc[(f.real_mask & 1) ? ptn : (int64_t)p];
+    }
+
+    int k = k_begin;
+    while (k < k_end) {
+        const int kn = ops[k].chunk_nops;
+        __syncthreads();
+        for (int t = threadIdx.x; t < kn * 2 * B; t += WG) {
+            const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B;
+            const CONST_AS DevOp &d = ops[k + o];
+            const double len = child ? d.right_len : d.left_len;
+            sReg[(child ? d.lds_right : d.lds_left) + e] = exp(A.eval[e] * (A.rates[0] * len));
+        }
+        __syncthreads();
+        if (!active) { k += kn; continue; }
+
+        for (int kk = 0; kk < kn; kk++, k++) {
+            const CONST_AS DevOp &op = ops[k];
+            const CONST_AS DevOp &nxop = ops[k + 1];
+            const int par = k & 1;
+            const bool leafL = op.left_kind == CHILD_LEAF, leafR = op.right_kind == CHILD_LEAF;
+            const double *exL = sReg + op.lds_left, *exR = sReg + op.lds_right;
+            int sc = 0, sL = 0, sR = 0;
+            if (leafL) sL = op.sl[ptn]; else sc += pfn_sc;
+            if (leafR) sR = op.sr[ptn];
+            double xr[KS];
+            if (op.right_kind == CHILD_LOAD) {
+                const double *src = op.ld + tbase;
+#pragma unroll
+                for (int s = 0; s < KS; s++) xr[s] = src[s * 64 + lane];
+                if (g == 0) prev_sc = op.ld_sc[ptn];
+            } else if (!leafR) {  // CHILD_PREV: gather the four waves' row blocks
+                double *xb = sX + par * KS * 64;
+#pragma unroll
+                for (int r = 0; r < 4; r++) xb[(4 * wave + r) * 64 + lane] = prev[r];
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < KS; s++) xr[s] = xb[s * 64 + lane];
+            } else {
+#pragma unroll
+                for (int s = 0; s < KS; s++) xr[s] = sTip[sR * N + 4 * s + g];
+            }
+            if (!leafR) sc += prev_sc;
+            const bool unkL = leafL && sL == A.state_unknown, unkR = leafR && sR == A.state_unknown;
+            // streamed child of the next op, requested while this one computes
+            const bool nreal = nxop.real_mask & 1;
+            const double *nsrc = nxop.pf + (nreal ? tbase : 0);
+            v4f64 YL = {0, 0, 0, 0}, YR = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                const int i = 4 * s + g;
+                const double vl = leafL ? sTip[sL * N + i] : PFn[s];
+                PFn[s] = nsrc[s * 64 + lane];
+                const double xl = vl * exL[i];
+                const double xrs = xr[s] * exR[i];
+                YL = __builtin_amdgcn_mfma_f64_16x16x4f64(aU[s], xl, YL, 0, 0, 0);
+                YR = __builtin_amdgcn_mfma_f64_16x16x4f64(aU[s], xrs, YR, 0, 0, 0);
+            }
+            if (g == 0) pfn_sc = nxop.pf_sc[nreal ? ptn : (int64_t)p];
+            double *tb = sT + par * KS * 64;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                tb[(4 * wave + r) * 64 + lane] = (unkL ? 1.0 : YL[r]) * (unkR ? 1.0 : YR[r]);
+            __syncthreads();
+            v4f64 O = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < KS; s++) O = __builtin_amdgcn_mfma_f64_16x16x4f64(aUi[s], tb[s * 64 + lane], O, 0, 0, 0);
+            double *dst = op.dst + tbase;
+            double lmax = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                dst[(size_t)(16 * wave + 4 * r + g) * 16 + p] = O[r];
+                lmax = fmax(lmax, fabs(O[r]));
+            }
+            prev = O;
+            lmax = fmax(lmax, __shfl_xor(lmax, 16, 64));
+            lmax = fmax(lmax, __shfl_xor(lmax, 32, 64));
+            if (g == 0) s_lmax[par][wave][p] = lmax;
+            __syncthreads();
+            lmax = fmax(fmax(s_lmax[par][0][p], s_lmax[par][1][p]), fmax(s_lmax[par][2][p], s_lmax[par][3][p]));
+            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0);
+            double my_scale = 0.0;
+            if (__any(do_scale)) {
+                if (do_scale) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        prev[r] *= kScalingThresholdInv;
+                        dst[(size_t)(16 * wave + 4 * r + g) * 16 + p] = prev[r];
+                    }
+                    sc += 1;
+                    if (lead && g == 0 && ptn < A.nptn) my_scale = kLogScalingThreshold * freq;
+                }
+            }
+            prev_sc = sc;
+            if (lead && g == 0) op.dst_sc[ptn] = (int16_t)sc;
+            const double ws = wave_sum_m(my_scale);
+            if (lead && lane == 0) A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
+        }
+    }
+}
+
+static hipError_t launch_trav_rows64(iqhip_engine *e, TravMArgs &A) {
+    constexpr int WG = 256;
+    const int nx = e->state_unknown + 1 - 64;
+    const size_t lds = (size_t)((64 + nx) * 64 + 4 * 16 * 64 + e->plan_lds_doubles) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma_rows64<WG>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    A.ngroups = (int)A.ntiles;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((k_traverse_mfma_rows64<WG>), dim3((unsigned)(A.ngroups * A.nsegs_launch)), dim3(WG), lds, e->stream, A);
+    return hipGetLastError();
+}
+
 // LDS doubles of k_traverse_mfma2 that do not depend on the plan (A images, tail images, U^-1 transposed)
 int mfma2_fixed_lds_doubles(int n) {
     const int mtf = n / 16, ks = n / 4;
@@ -757,7 +927,7 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs
     if (e->mfma_pipelined) {  // plan was built in canonical (PF, PREV) form
         if (e->n == 20 && e->ncat == 4) return e->cat_split ? launch_trav_m2<20, 1, 4>(e, A) : launch_trav_m2<20, 4>(e, A);
         if (e->n == 20 && e->ncat == 1) return launch_trav_m2<20, 1>(e, A);
-        if (e->n == 64 && e->ncat == 1) return launch_trav_m2<64, 1>(e, A);
+        if (e->n == 64 && e->ncat == 1) return e->row_split ? launch_trav_rows64(e, A) : launch_trav_m2<64, 1>(e, A);
         return hipErrorInvalidValue;
     }
     switch (e->n) {

@@ -769,3 +769,22 @@ def test_category_split_gives_identical_vectors(pkg, synth, oracle, ntaxa, kw, m
     assert x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]) and x[3] == y[3]
     if "caterpillar" in kw:
         assert x[2].max() >= 1
+
+
+@pytest.mark.parametrize("ntaxa,kw", [(16, dict(missing=0.04)), (90, dict(lo=0.3, hi=0.7, caterpillar=True))])
+def test_row_split_gives_identical_vectors(pkg, synth, oracle, ntaxa, kw, monkeypatch):
+    """64-state kernel, one wave per 16 output rows of a tile (small alignments) against one wave per tile."""
+    out = []
+    for rs in ("0", "1"):
+        monkeypatch.setenv("IQHIP_ROW_SPLIT", rs)
+        t, ot, *_ = make_case(synth, oracle, pkg, ntaxa, 150, 64, 1, 7100 + ntaxa, seq_type=2, **kw)
+        lnl = t.compute_likelihood()
+        a, b = t.current_branch()
+        out.append((lnl, t.fetch_partial(a, b), t.fetch_scale_num(a, b), t.neighbor_info(a, b)["lh_scale_factor"]))
+        ref, _ = ot.likelihood()
+        assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+        assert check_all_vectors(t, ot) == ntaxa - 2
+    x, y = out
+    assert x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]) and x[3] == y[3]
+    if "caterpillar" in kw:
+        assert x[2].max() >= 1
