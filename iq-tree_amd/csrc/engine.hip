@@ -50,8 +50,8 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
         return fail(IQHIP_ERR_UNSUPPORTED,
                     "iqhip_create: nstates must be 4, 20 or 64 (the reference's SIMD dispatch cases; "
                     "other counts use its scalar kernel)");
-    if (nstates == 4 && !(ncat >= 1 && ncat <= 8 && ncat != 7))
-        return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_create: 4-state path supports ncat in {1..6,8}");
+    if (nstates == 4 && !(ncat >= 1 && ncat <= 8))
+        return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_create: 4-state path supports ncat in {1..8}");
     if (nstates != 4 && ncat > (nstates == 20 ? 96 : 16))  // 20 states: (class, rate) components of mixtures
         return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_create: ncat must be <= 16 (<= 96 components for 20 states)");
     int ndev = 0;

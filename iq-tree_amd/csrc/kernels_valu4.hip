@@ -537,6 +537,7 @@ hipError_t launch_traverse4(iqhip_engine *e, const int *seg_table, int nsegs, bo
         case 4: return launch_trav_wg<4>(e, A);
         case 5: return launch_trav_wg<5>(e, A);
         case 6: return launch_trav_wg<6>(e, A);
+        case 7: return launch_trav_wg<7>(e, A);
         case 8: return launch_trav_wg<8>(e, A);
         default: return hipErrorInvalidValue;
     }
@@ -580,7 +581,7 @@ hipError_t launch_theta4(iqhip_engine *e, const DevBranch &br) {
                            e->state_unknown, e->d_theta, e->ntiles);                       \
         break;
     switch (e->ncat) {
-        IQ_THETA(1) IQ_THETA(2) IQ_THETA(3) IQ_THETA(4) IQ_THETA(5) IQ_THETA(6) IQ_THETA(8)
+        IQ_THETA(1) IQ_THETA(2) IQ_THETA(3) IQ_THETA(4) IQ_THETA(5) IQ_THETA(6) IQ_THETA(7) IQ_THETA(8)
         default: return hipErrorInvalidValue;
     }
 #undef IQ_THETA
@@ -680,7 +681,7 @@ static hipError_t launch_theta_reduce(iqhip_engine *e, double len, int nwaves) {
                            e->nptn - e->n_unobs, e->theta_a_sc, e->theta_b_sc);                \
         break;
     switch (e->ncat) {
-        IQ_TR(1) IQ_TR(2) IQ_TR(3) IQ_TR(4) IQ_TR(5) IQ_TR(6) IQ_TR(8)
+        IQ_TR(1) IQ_TR(2) IQ_TR(3) IQ_TR(4) IQ_TR(5) IQ_TR(6) IQ_TR(7) IQ_TR(8)
         default: return hipErrorInvalidValue;
     }
 #undef IQ_TR

@@ -51,7 +51,7 @@ def check_all_vectors(t, ot):
     return nchecked
 
 
-@pytest.mark.parametrize("ncat", [1, 2, 3, 4, 5, 6, 8])
+@pytest.mark.parametrize("ncat", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_dna_full_traversal_all_ncat(pkg, synth, oracle, ncat):
     t, ot, *_ = make_case(synth, oracle, pkg, 14, 700, 4, ncat, 100 + ncat, missing=0.05)
     t.clear_all_partial_lh()
