@@ -1095,7 +1095,11 @@ extern "C" int iqhip_optimize_branch_batch(iqhip_engine *e, const iqhip_branch_t
         if (rc) return rc;
     }
     // workgroups per task: every workgroup of a launch must be resident (grid barrier inside each task)
-    const int capacity = e->num_cus * 4;
+    // ... which bounds the batch by what fits the chip at once: at most 4 workgroups per CU, fewer when the
+    // kernel's LDS (3 val arrays of a block) does not allow four
+    const size_t newton_lds = (size_t)(3 * e->block + 8) * sizeof(double) + 64;
+    const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(150 * 1024) / newton_lds));
+    const int capacity = e->num_cus * wg_per_cu;
     const int wgs_needed = (int)std::max<int64_t>(1, (e->ntiles + 3) / 4);
     const int chunk = std::min(ntasks, capacity);             // tasks per launch
     const int G = std::max(1, std::min(wgs_needed, capacity / chunk));
@@ -1117,7 +1121,7 @@ extern "C" int iqhip_optimize_branch_batch(iqhip_engine *e, const iqhip_branch_t
         e->d_batch_barriers = nullptr;
         e->d_batch_tasks = nullptr;
         e->batch_cap = 0;
-        HIPCHK(dmalloc(&e->d_batch_partials, (size_t)chunk * 4 * capacity));
+        HIPCHK(dmalloc(&e->d_batch_partials, (size_t)chunk * 4 * (e->num_cus * 4)));
         HIPCHK(dmalloc(&e->d_batch_out, (size_t)chunk * 6));
         HIPCHK(dmalloc(&e->d_batch_barriers, (size_t)2 * chunk));
         HIPCHK(hipMalloc(&e->d_batch_tasks, newton_task_bytes() * (size_t)chunk));
