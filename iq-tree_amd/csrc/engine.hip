@@ -1095,10 +1095,10 @@ extern "C" int iqhip_optimize_branch_batch(iqhip_engine *e, const iqhip_branch_t
         if (rc) return rc;
     }
     // workgroups per task: every workgroup of a launch must be resident (grid barrier inside each task)
-    // ... which bounds the batch by what fits the chip at once: at most 4 workgroups per CU, fewer when the
-    // kernel's LDS (3 val arrays of a block) does not allow four
+    // ... which bounds the batch by what fits the chip at once: 3 workgroups per CU (k_newton_batch: 125 VGPRs, i.e.
+    // four waves per SIMD would fit exactly -- keep a margin), fewer when its LDS (3 val arrays of a block) says so
     const size_t newton_lds = (size_t)(3 * e->block + 8) * sizeof(double) + 64;
-    const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(150 * 1024) / newton_lds));
+    const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(3, (size_t)(150 * 1024) / newton_lds));
     const int capacity = e->num_cus * wg_per_cu;
     const int wgs_needed = (int)std::max<int64_t>(1, (e->ntiles + 3) / 4);
     const int chunk = std::min(ntasks, capacity);             // tasks per launch
