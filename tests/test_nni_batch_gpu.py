@@ -91,3 +91,46 @@ def test_compute_all_partial_lh_is_one_submission(pkg, synth, oracle):
             if a < b:
                 assert abs(t.compute_likelihood_branch(a, b) - lnl) <= LNL_RTOL * abs(lnl)
     assert t.last_plan() == []
+
+
+def test_batch_and_consumer_entry_points_reject_bad_input(pkg, synth, oracle):
+    """error behaviour of the newer entry points: int status + message, nothing launched on bad input."""
+    import ctypes as C
+    lib = pkg.libiqhip()
+
+    class Task(C.Structure):
+        _fields_ = [("ops", C.c_void_p), ("nops", C.c_int32), ("max_steps", C.c_int32), ("a", pkg.BranchEnd), ("b", pkg.BranchEnd),
+                    ("xguess", C.c_double), ("x1", C.c_double), ("x2", C.c_double), ("xacc", C.c_double)]
+
+    class Result(C.Structure):
+        _fields_ = [("optx", C.c_double), ("d2l", C.c_double), ("lnl", C.c_double), ("nsteps", C.c_int32), ("status", C.c_int32)]
+
+    lib.iqhip_optimize_branch_batch.argtypes = [C.c_void_p, C.POINTER(Task), C.c_int, C.POINTER(C.c_double), C.POINTER(Result)]
+    lib.iqhip_pattern_lh_cat.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_double)]
+    t, ot, *_ = make_case(synth, oracle, pkg, 8, 100, 4, 4, 8080, mem_mode=pkg.LM_ALL_BRANCH)
+    t.compute_likelihood()
+    a, b = t.current_branch()
+    inner = [(x, y) for x in range(t.num_nodes) for y, _ in t.neighbors(x) if not ot.is_leaf(x) and not ot.is_leaf(y)]
+    x, y = inner[0]
+    t.compute_all_partial_lh()
+    kx, ky = t.neighbor_info(x, y)["key"], t.neighbor_info(y, x)["key"]
+    res = (Result * 1)()
+    good = Task(None, 0, 10, pkg.key_end(kx), pkg.key_end(ky), 0.1, 1e-6, 100.0, 1e-6)
+    assert lib.iqhip_optimize_branch_batch(t.engine, (Task * 1)(good), 1, None, res) == 0
+    assert res[0].status == 0 and 1e-6 <= res[0].optx <= 100.0 and np.isfinite(res[0].lnl)
+    # the same branch through the single-branch evaluator
+    t.optimize_one_branch(x, y, clear_lh=False)
+    assert abs(t.neighbor_info(x, y)["length"] - res[0].optx) <= 5e-6     # both stop within xacc of the optimum
+    for bad in (Task(None, 0, 0, pkg.key_end(kx), pkg.key_end(ky), 0.1, 1e-6, 100.0, 1e-6),       # max_steps < 1
+                Task(None, 0, 10, pkg.key_end(kx), pkg.key_end(ky), 0.1, 1.0, 0.5, 1e-6),         # x2 <= x1
+                Task(None, 0, 10, pkg.key_end(0xabcdef), pkg.key_end(ky), 0.1, 1e-6, 100.0, 1e-6),  # unknown key
+                Task(None, 2, 10, pkg.key_end(kx), pkg.key_end(ky), 0.1, 1e-6, 100.0, 1e-6)):     # nops without ops
+        assert lib.iqhip_optimize_branch_batch(t.engine, (Task * 1)(bad), 1, None, res) != 0
+        assert len(lib.iqhip_last_error()) > 0
+    assert lib.iqhip_optimize_branch_batch(t.engine, None, 1, None, res) != 0
+    out = np.zeros(t.nptn * 4)
+    dp = out.ctypes.data_as(C.POINTER(C.c_double))
+    t2, *_ = make_case(synth, oracle, pkg, 8, 100, 4, 4, 8081)
+    t2.compute_likelihood()
+    assert lib.iqhip_pattern_lh_cat(t2.engine, 0.1, dp) != 0 and b"compute_theta" in lib.iqhip_last_error()
+    assert lib.iqhip_pattern_lh_cat(t.engine, -1.0, dp) != 0
