@@ -58,6 +58,7 @@ def main():
                     help="exercise the N>1 path (RCCL all-reduce of the result vector) even with one rank")
     ap.add_argument("--reference-order", action="store_true",
                     help="plan subtrees in the reference's neighbour order instead of heavier-first")
+    ap.add_argument("--ncat", type=int, default=0, help="rate categories (dna / protein workloads; default: the BASELINE shape)")
     args = ap.parse_args()
 
     import torch
@@ -95,6 +96,8 @@ def main():
               # protein profile mixture x Gamma (C10+G4 shape: 10 classes x 4 rates = 40 components)
               "mixture": (50, 10000, 20, 40, pkg.SEQ_PROTEIN)}
     T0, P0, nst, ncat, seq_type = shapes[args.workload]
+    if args.ncat and args.workload in ("dna", "protein"):
+        ncat = args.ncat
     T, P = args.ntaxa or T0, args.patterns or P0
     sim_model = None
     if args.workload == "mixture":
@@ -102,7 +105,7 @@ def main():
         sim_model = model.classes[0]
     elif nst == 4:
         model = synth.gtr_model(rates6=(1.5, 2.4, 1.8, 1.9, 2.8, 1.0), freqs=(0.25, 0.26, 0.25, 0.24),
-                                alpha=0.9, ncat=4)
+                                alpha=0.9, ncat=ncat)
     else:
         # random reversible 20-/64-state model of the LG+G4 / GY shape (the reference's empirical
         # matrices are constants of its source and are not copied); codon: ncat = 1 as GY+F1X4

@@ -387,7 +387,8 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
     e->d_evalc = e->d_model + o_evalc;
     e->d_tipc = e->d_model + o_tipc;
     e->d_cls = reinterpret_cast<int *>(e->d_model + o_cls);
-    if (nclass > 1) {
+    if (nclass > 1 || (e->n == 20 && !e->mfma_pipelined_ok)) {  // (20 states with a category count that has no
+        // pipelined instantiation also run on the mixture kernel: one class)
         // MFMA A-operand images of every class for k_traverse_mfma_mix20: [class][U16 | U4 | Ui16 | Ui4][s][lane]
         // (16-row tile: row = lane & 15; 4-row tail: row = 16 + (lane & 3); k = 4s + (lane >> 4)), followed by
         // the padded two-tile images [class][U | U^-1][m][s][lane] of the generic kernel (IQHIP_MIX_GENERIC)

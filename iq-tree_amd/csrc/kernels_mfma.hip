@@ -700,8 +700,9 @@ static hipError_t launch_trav_mix20_cs(iqhip_engine *e, TravMArgs &A) {
 }
 
 static hipError_t launch_trav_mix20(iqhip_engine *e, TravMArgs &A) {
-    // component split while the alignment is small (fewer than two tiles per SIMD) and the components divide by 4
-    bool split = (e->ncat % 4 == 0) && e->ntiles < 2 * (int64_t)e->num_cus * 4;
+    // component split while the alignment is small (at most 3/4 tile per SIMD: 10k patterns x 40 components 1.96 ->
+    // 1.77 ms, but 30k patterns x 8 components 1.78 -> 2.62 ms) and the components divide by 4
+    bool split = (e->ncat % 4 == 0) && 4 * e->ntiles <= 3 * (int64_t)e->num_cus * 4;
     if (const char *cs = getenv("IQHIP_CAT_SPLIT")) split = (atoi(cs) != 0) && (e->ncat % 4 == 0);
     return split ? launch_trav_mix20_cs<4>(e, A) : launch_trav_mix20_cs<1>(e, A);
 }
@@ -933,6 +934,9 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs
     switch (e->n) {
         case 20:
             if (e->nclass > 1) return getenv("IQHIP_MIX_GENERIC") ? launch_trav_m<20, true>(e, A) : launch_trav_mix20(e, A);
+            // plain model, category count without a pipelined instantiation (+G8, +R5, ...): the mixture kernel
+            // with one class (16+4-row MFMA split, A fragments in registers) beats the padded generic kernel
+            if (e->d_img && !getenv("IQHIP_MIX_GENERIC")) return launch_trav_mix20(e, A);
             return launch_trav_m<20, false>(e, A);
         case 64: return launch_trav_m<64, false>(e, A);
         default: return hipErrorInvalidValue;
