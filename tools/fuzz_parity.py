@@ -67,6 +67,13 @@ for case in range(ncases):
             ot.set_length(x, y, t.neighbor_info(x, y)["length"])
             r2, _ = ot.likelihood()
             assert abs(t.compute_likelihood() - r2) <= 1e-8 * abs(r2), ("after optimise", r2)
+        if mem == 1 and ntaxa >= 5 and rng.random() < 0.7:   # batched NNI evaluation against the branch-by-branch evaluator
+            nni5 = rng.random() < 0.5
+            batch = t.evaluate_nnis5_batch() if nni5 else t.evaluate_nnis_batch()
+            k = 2 * int(rng.integers(len(batch) // 2))
+            seqm = t.nni_for_branch(batch[k]["node1"], batch[k]["node2"], nni5=nni5)
+            for c in range(2):
+                assert abs(batch[k + c]["newloglh"] - seqm[c][0]) <= 1e-9 * abs(seqm[c][0]), ("nni", nni5, k + c)
         t.close()
         print("ok  ", desc)
     except Exception as e:  # noqa
