@@ -81,7 +81,9 @@ int iqhip_device_count(void);
 
 /* nstates in {4, 20, 64} (the reference's SIMD dispatch cases phylotreeavx.cpp:34-134;
  * 2 and other counts use the scalar kernel there and are IQHIP_ERR_UNSUPPORTED here).
- * nptn = aln->size() + unobserved patterns of this shard; ntaxa = leafNum. */
+ * nptn = aln->size() + unobserved patterns of this shard; ntaxa = leafNum.
+ * ncat: 1..8 for 4 states; 1..16 for 64 states; 1..96 for 20 states (the (class, rate) components of a mixture
+ * model count as categories, see iqhip_set_mixture_model). */
 int iqhip_create(iqhip_engine **out, int device, int nstates, int ncat, int64_t nptn,
                  int ntaxa);
 void iqhip_destroy(iqhip_engine *e);
