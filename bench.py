@@ -5,16 +5,26 @@ Step  = the reference's hot loop 1: clearAllPartialLH(); computeLikelihood()  (S
         invalidate everything, full post-order traversal (ntaxa-2 node updates), root-branch lnL.
         Driven through the host mirror -> C ABI (include/iqhip.h) -> HIP kernels.
 Value = steps * (ntaxa-2) * patterns(all ranks) / wall / 1e6   (internal nodes only).
-N=1   : BASELINE.json configs[1]: synthetic DNA 50 taxa x 100k patterns, GTR+G4.
-N>1   : weak scaling -- every rank holds its own 100k-pattern shard of one (N*100k)-pattern
-        alignment on the same tree; one RCCL all-reduce (SUM, f64) of the device result vector
-        {lnL, sum_scale per node} per step.
-Inputs are resident in HBM before the timed region.  One JSON line on rank 0.
+
+Workloads (iq-tree_amd/synth.py BASELINE_SHAPES):
+  dna      BASELINE configs[1]: DNA 50 taxa x 100k patterns per GPU, GTR+G4 -- the headline; weak scaling
+           (every rank holds its own 100k-pattern shard of one N*100k-pattern alignment, same tree)
+  protein  configs[2]: 20-state 100 x 50k +G4 (per GPU, weak)
+  dna4     configs[3]: DNA 200 taxa x 1M patterns, pattern-sharded: 1M/N per GPU (strong scaling)
+  codon    configs[4]: 64-state 50 x 20k, 20k/N per GPU (strong scaling)
+One RCCL all-reduce (SUM, f64) of the device result vector {lnL, sum_scale per node} per step when N > 1
+(SURVEY.md 8e).  Inputs are resident in HBM before the timed region.  One JSON line on rank 0; with the default
+workload the line also carries the configs[3] / configs[4] results of the same N under "also" (--no-also skips).
+
+`python bench.py --gpus N` without WORLD_SIZE in the environment starts its N ranks itself (fresh child
+processes through torch.distributed.run, before this process touches a GPU).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,16 +34,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0  # ... "6.29 TB/s measured (float4 copy)": what floor_ms is priced against
 # fp64 matrix peak: the guide's MFMA table has no f64 row; MI355X datasheet value,
 # equal to the fp64 vector peak on this chip
 MFMA_F64_PEAK_TFLOPS = 78.6
+STRONG = ("dna4", "codon")  # total pattern count fixed, split over the ranks
 
 
 def algorithmic_bytes_per_traversal(ntaxa, nptn, block):
     """P*[(2T-4)*V + (2T-4)*2 + T*1 + 8 + 16], V = block*8."""
     V = block * 8
     return nptn * ((2 * ntaxa - 4) * V + (2 * ntaxa - 4) * 2 + ntaxa + 8 + 16)
+
+
+def design_min_bytes_per_traversal(ntaxa, nptn, block):
+    """What the fused whole-plan-per-launch design cannot avoid moving: every internal vector and its counters
+    written once (T-2), the vectors that are neither the previous result nor register-parked re-read (not counted
+    here: plan dependent), leaf states read once, _pattern_lh written, ptn_freq / ptn_invar read."""
+    V = block * 8
+    return nptn * ((ntaxa - 2) * (V + 2) + ntaxa + 8 + 16)
 
 
 def algorithmic_flops_per_traversal(ntaxa, nptn, n, ncat):
@@ -43,85 +63,101 @@ def algorithmic_flops_per_traversal(ntaxa, nptn, n, ncat):
     return nptn * ncat * ((ntaxa - 2) * (2 * n * n + n) + (ntaxa - 3) * 2 * n * n)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["dna", "protein", "codon", "mixture"], default="dna",
-                    help="dna = BASELINE configs[1] (the headline); protein/codon = configs[2]/[4] shapes")
-    ap.add_argument("--ntaxa", type=int, default=0)
-    ap.add_argument("--patterns", type=int, default=0, help="patterns per GPU")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-collective", action="store_true",
-                    help="exercise the N>1 path (RCCL all-reduce of the result vector) even with one rank")
-    ap.add_argument("--reference-order", action="store_true",
-                    help="plan subtrees in the reference's neighbour order instead of heavier-first")
-    ap.add_argument("--ncat", type=int, default=0, help="rate categories (dna / protein workloads; default: the BASELINE shape)")
-    args = ap.parse_args()
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
-    import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the likelihood path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    collective = world > 1 or args.force_collective
-    real_stdout = os.dup(1)
-    if collective:
-        # RCCL prints a version banner on stdout at communicator creation: keep stdout clean for the
-        # single JSON line by pointing fd 1 at stderr until the result is printed
-        sys.stdout.flush()
-        os.dup2(2, 1)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the N ranks as fresh child processes (this process has not touched the
+    GPU and never will) and pass rank 0's JSON line through."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
-    pkg = entry.load_package()
-    import importlib
-    synth = importlib.import_module("iqtree_amd.synth")
+
+class Dist:
+    """torch.distributed plumbing of one rank (backend nccl = RCCL)."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit("WORLD_SIZE %d != --gpus %d" % (self.world, args.gpus))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the likelihood path has no CPU fallback")
+        torch.cuda.set_device(self.local_rank)
+        self.collective = self.world > 1 or args.force_collective
+        self.dist = None
+        if self.collective:
+            import torch.distributed as dist
+            self.dist = dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                    device_id=torch.device("cuda", self.local_rank))
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.collective:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, v):
+        if not self.collective:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def enable_collective(tree, D, lib):
+    """Sharded run: the engine works on torch's current stream and leaves each result vector in a torch-owned device
+    buffer, which is all-reduced over RCCL before the single host read."""
+    torch = D.torch
+    stream = torch.cuda.current_stream()
+    assert lib.iqhip_set_stream(tree.engine, C.c_void_p(stream.cuda_stream)) == 0
+    res = torch.zeros(2 + 4096, dtype=torch.float64, device="cuda")
+    assert lib.iqhip_bind_result_buffer(tree.engine, C.c_void_p(res.data_ptr()), res.numel()) == 0
+
+    def hook(ptr, n):
+        assert ptr == res.data_ptr()
+        D.dist.all_reduce(res[:n], op=D.dist.ReduceOp.SUM)
+    tree._collective_buffer = res
+    tree.set_allreduce_hook(hook)
+
+
+def kernel_name(pkg, nst, ncat, nclass):
+    if nst == 4:
+        return "k_traverse4<%d,256>" % ncat
+    if nclass > 1 or (nst == 20 and ncat not in (1, 4)):
+        return "k_traverse_mfma_mix20<256>"
+    if (nst, ncat) in ((20, 4), (20, 1), (64, 1)):
+        return "k_traverse_mfma2<%d,%d,256>" % (nst, ncat)
+    return "k_traverse_mfma<%d,256>" % nst
+
+
+def run_workload(args, D, pkg, synth, workload, steps, warmup, with_cpu_baseline):
+    """-> the JSON object of one workload at this world size (rank 0 gets the full object)."""
     lib = pkg.libiqhip()
-
-    shapes = {"dna": (50, 100000, 4, 4, pkg.SEQ_DNA), "protein": (100, 50000, 20, 4, pkg.SEQ_PROTEIN),
-              "codon": (50, 20000, 64, 1, pkg.SEQ_CODON),
-              # protein profile mixture x Gamma (C10+G4 shape: 10 classes x 4 rates = 40 components)
-              "mixture": (50, 10000, 20, 40, pkg.SEQ_PROTEIN)}
-    T0, P0, nst, ncat, seq_type = shapes[args.workload]
-    if args.ncat and args.workload in ("dna", "protein"):
-        ncat = args.ncat
-    T, P = args.ntaxa or T0, args.patterns or P0
-    sim_model = None
-    if args.workload == "mixture":
-        model = synth.mixture_model(20, 10, 7, alpha=0.9, ncat=4)
-        sim_model = model.classes[0]
-    elif nst == 4:
-        model = synth.gtr_model(rates6=(1.5, 2.4, 1.8, 1.9, 2.8, 1.0), freqs=(0.25, 0.26, 0.25, 0.24),
-                                alpha=0.9, ncat=ncat)
-    else:
-        # random reversible 20-/64-state model of the LG+G4 / GY shape (the reference's empirical
-        # matrices are constants of its source and are not copied); codon: ncat = 1 as GY+F1X4
-        model = synth.random_reversible_model(nst, 7, alpha=0.9 if ncat > 1 else None, ncat=ncat,
-                                              min_freq=1e-4)
-    # same tree on every rank (seed 1); each rank simulates its own shard of sites
-    nwk = synth.random_tree_newick(T, 1)
-    nsites = int(P * 1.02) + 64
-    while True:
-        st = synth.simulate_alignment(nwk, sim_model or model, nsites, 1000 + rank)
-        pat, freq = synth.compress_patterns(st)
-        if pat.shape[1] >= P:
-            break
-        nsites = int(nsites * 1.3)
-    pat = np.ascontiguousarray(pat[:, :P])
-    freq = freq[:P].copy()
+    torch = D.torch
+    T0, P0, nst, ncat0, seq_type = synth.BASELINE_SHAPES[workload]
+    T = args.ntaxa or T0
+    P = args.patterns or P0
+    strong = workload in STRONG and not args.patterns
+    if strong:
+        P = (P0 + D.world - 1) // D.world
+    ncat = args.ncat if (args.ncat and workload in ("dna", "protein", "dna4")) else 0
+    nwk, pat, freq, model = synth.baseline_workload(workload, ntaxa=T, patterns=P, shard=D.rank, ncat=ncat)
 
     tree = pkg.PhyloTree(nwk)
     tree.set_alignment(nst, seq_type, pat, freq)
@@ -129,54 +165,50 @@ def main():
     tree.set_likelihood_kernel(pkg.LK_EIGEN_HIP)
     if args.reference_order:
         tree.set_heavy_first(False)
-    tree.attach_engine(local_rank)
+    tree.attach_engine(D.local_rank)
     eng = tree.engine
-    res = None
-    if collective:
-        # sharded run: the engine works on torch's current stream and leaves each result vector in a
-        # torch-owned device buffer, which is all-reduced over RCCL before the single host read
-        stream = torch.cuda.current_stream()
-        assert lib.iqhip_set_stream(eng, C.c_void_p(stream.cuda_stream)) == 0
-        res = torch.zeros(2 + 4096, dtype=torch.float64, device="cuda")
-        assert lib.iqhip_bind_result_buffer(eng, C.c_void_p(res.data_ptr()), res.numel()) == 0
-
-        def hook(ptr, n):
-            assert ptr == res.data_ptr()
-            dist.all_reduce(res[:n], op=dist.ReduceOp.SUM)
-        tree.set_allreduce_hook(hook)
+    if D.collective:
+        enable_collective(tree, D, lib)
 
     def step():  # clearAllPartialLH(); computeLikelihood() on the C++ side of the boundary
         return tree.clear_and_compute_likelihood()
 
-    def barrier():
-        torch.cuda.synchronize()
-        if collective:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
+    lnl = None
+    for _ in range(warmup):
         lnl = step()
-    barrier()
+    D.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         lnl = step()
-    barrier()
-    dt = time.perf_counter() - t0
+    D.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0)
+
+    # sustained leg (not the reported value): the same step back to back for --sustain-seconds, so that a
+    # power / activity sampler sees the region; the K-step region above can be a few milliseconds long
+    sustained = None
+    if args.sustain_seconds > 0:
+        nrep = max(steps, int(args.sustain_seconds / max(dt / steps, 1e-6)))
+        nrep = int(D.max_over_ranks(float(nrep)))
+        D.barrier()
+        t1 = time.perf_counter()
+        for _ in range(nrep):
+            step()
+        D.barrier()
+        dts = D.max_over_ranks(time.perf_counter() - t1)
+        sustained = {"steps": nrep, "seconds": dts, "value": nrep * (T - 2) * P * D.world / dts / 1e6,
+                     "ms_per_step": dts / nrep * 1e3}
+
     # dominant-kernel duration: HIP events on the launch stream around that kernel, measured live in
-    # a second pass of the same steps (kept out of the timed region: two event records per step)
+    # a further pass of the same steps (kept out of the timed region: two event records per step)
     lib.iqhip_timing_enable(eng, 1)
-    ntimed = min(args.steps, 100)
+    ntimed = min(max(steps, 20), 100)
     for _ in range(ntimed):
         step()
     avg_ms, launches = C.c_double(), C.c_int64()
     lib.iqhip_timing_read(eng, C.byref(avg_ms), C.byref(launches), 1)
     lib.iqhip_timing_enable(eng, 0)
-    if collective:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
 
-    updates = args.steps * (T - 2) * P * world
+    updates = steps * (T - 2) * P * D.world
     value = updates / dt / 1e6
     block = nst * model.ncat
     # one traversal = one launch of the traversal kernel, or two for a staged plan (independent subtrees,
@@ -185,7 +217,6 @@ def main():
     algo_bytes = algorithmic_bytes_per_traversal(T, P, block) / lpt
     kern_s = avg_ms.value * 1e-3
     achieved = algo_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
-
     algo_flops = algorithmic_flops_per_traversal(T, P, nst, model.ncat) / lpt
     if nst == 64:
         tf = algo_flops / kern_s / 1e12 if kern_s > 0 else 0.0
@@ -200,60 +231,131 @@ def main():
     # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     # (tools/profile_round.sh -> profiles/traffic.json); null when the shape was not profiled
     try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(args.workload)
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(workload)
         if tr and tr["ntaxa"] == T and tr["patterns_per_gpu"] == P and tr["ncat"] == model.ncat:
             roof["traffic"] = tr["hbm_traffic_bytes_per_launch"]
             roof["traffic_source"] = tr["source"]
+            # the counter-based figure beside the algorithmic one: bytes that really crossed the memory fabric
+            if kern_s > 0:
+                roof["frac_counter"] = tr["hbm_traffic_bytes_per_launch"] / kern_s / 1e9 / HBM_PEAK_GBS
     except Exception:
         pass
-    roof.update({"kernel": "k_traverse4<4,256>" if nst == 4 else "k_traverse_mfma2<%d,%d,256>" % (nst, model.ncat),
+    floor_bytes = design_min_bytes_per_traversal(T, P, block)
+    roof.update({"kernel": kernel_name(pkg, nst, model.ncat, int(getattr(model, "nclass", 1))),
                  "kernel_avg_ms": avg_ms.value, "launches": launches.value, "launches_per_traversal": lpt,
-                 "kernel_ms_per_traversal": avg_ms.value * lpt})
+                 "kernel_ms_per_traversal": avg_ms.value * lpt,
+                 # the design's own HBM floor: bytes it cannot avoid / the measured-achievable 6.3 TB/s
+                 "floor_ms": floor_bytes / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3,
+                 "floor_bytes_per_traversal": floor_bytes})
     out = {
         "metric": "million pattern-node partial-likelihood updates/sec",
         "value": value,
         "unit": "M updates/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "n_gpus": D.world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "%s %d taxa x %d patterns/GPU, %s, fixed tree: clearAllPartialLH + "
-                               "full traversal + root-branch lnL" % (args.workload.upper(), T, P, model.name),
-                   "ntaxa": T, "patterns_per_gpu": P, "nstates": nst, "ncat": model.ncat,
-                   "parallelism": "patterns sharded over %d GPU(s), 1 RCCL all-reduce/step" % world},
+                               "full traversal + root-branch lnL" % (workload.upper(), T, P, model.name),
+                   "ntaxa": T, "patterns_per_gpu": P, "patterns_total": P * D.world, "nstates": nst,
+                   "ncat": model.ncat,
+                   "parallelism": "patterns sharded over %d GPU(s), 1 RCCL all-reduce/step" % D.world},
         "lnL": lnl,
+        "host_overhead_ms_per_step": dt / steps * 1e3 - avg_ms.value * lpt,
         "roofline": roof,
     }
+    if sustained:
+        out["sustained"] = sustained
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the CPU baseline is timed at N = 1 only
+    if D.rank == 0 and D.world == 1 and with_cpu_baseline:
+        # The oracle on the WHOLE workload: parity of this very run (lnL delta, root-side counters), then the CPU
+        # baseline timed on the same input (bounded by --cpu-seconds; a traversal takes 0.06 .. 10 s)
         od = entry.load_oracle()
-        sample = min(P, 100000 if nst == 4 else (4000 if model.ncat <= 4 else 1000))
-        ot = od.OracleTree(nwk, nst, seq_type, pat[:, :sample], freq[:sample], None, model)
+        ot = od.OracleTree(nwk, nst, seq_type, pat, freq, None, model)
         try:
             ncores = min(len(os.sched_getaffinity(0)), 16)
         except AttributeError:
             ncores = min(os.cpu_count() or 1, 16)
+        ncores = od.lib().oracle_set_threads(ncores)
+        olnl, (a, b) = ot.likelihood()
+        frm, to = (a, b) if not ot.is_leaf(b) else (b, a)
+        osc = ot.partial(frm, to)[1]
+        gsc = tree.fetch_scale_num(frm, to)
+        out["lnl_oracle"] = olnl
+        out["lnl_rel_delta_vs_oracle"] = abs(lnl - olnl) / abs(olnl)
+        out["scale_num_mismatches"] = int((gsc != osc).sum())
+        out["scale_num_sum"] = int(osc.astype(np.int64).sum())
+        mups, reps, secs = ot.time_traversals(budget_s=args.cpu_seconds * 0.6)
         od.lib().oracle_set_threads(1)
         mups1, reps1, secs1 = ot.time_traversals(budget_s=args.cpu_seconds * 0.4)
-        ncores = od.lib().oracle_set_threads(ncores)
-        mups, reps, secs = ot.time_traversals(budget_s=args.cpu_seconds * 0.6)
-        olnl, _ = ot.likelihood()
         out["cpu_baseline"] = {"value": mups, "unit": "M updates/s", "cores": ncores, "kind": "port",
                                "sample": "oracle/lh_oracle.c (gcc -O3 -mavx -fopenmp, pattern loop threaded as the "
-                                         "reference's '#pragma omp parallel for'): %d traversals of the same tree on the "
-                                         "first %d patterns in %.1f s with %d threads; 1 thread: %.2f M updates/s "
-                                         "(%d traversals in %.1f s)" % (reps, sample, secs, ncores, mups1, reps1, secs1)}
+                                         "reference's '#pragma omp parallel for'): %d traversals of the same tree on all "
+                                         "%d patterns of the workload in %.1f s with %d threads; 1 thread: %.2f M updates/s "
+                                         "(%d traversals in %.1f s)" % (reps, P, secs, ncores, mups1, reps1, secs1)}
+    tree.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", choices=["dna", "protein", "codon", "mixture", "dna4"], default="dna",
+                    help="dna = BASELINE configs[1] (the headline); protein / dna4 / codon = configs[2] / [3] / [4]")
+    ap.add_argument("--ntaxa", type=int, default=0)
+    ap.add_argument("--patterns", type=int, default=0, help="patterns per GPU (overrides the workload's count)")
+    ap.add_argument("--cpu-seconds", type=float, default=14.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true",
+                    help="default workload only: skip the configs[3] (dna4) and configs[4] (codon) results under 'also'")
+    ap.add_argument("--also", action="store_true", help="add the 'also' results to a non-default workload / N = 1 run")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+                    help="after the timed K steps, repeat the step for this long (activity evidence; 0 = off)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="exercise the N>1 path (RCCL all-reduce of the result vector) even with one rank")
+    ap.add_argument("--reference-order", action="store_true",
+                    help="plan subtrees in the reference's neighbour order instead of heavier-first")
+    ap.add_argument("--ncat", type=int, default=0, help="rate categories (dna / protein workloads; default: the BASELINE shape)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    real_stdout = os.dup(1)
+    # RCCL prints a version banner on stdout at communicator creation: keep stdout clean for the single JSON line
+    sys.stdout.flush()
+    os.dup2(2, 1)
+    D = Dist(args)
+    pkg = entry.load_package()
+    import importlib
+    synth = importlib.import_module("iqtree_amd.synth")
+
+    out = run_workload(args, D, pkg, synth, args.workload, args.steps, args.warmup, not args.no_cpu_baseline)
+    # the multi-GPU configs north_star names, at this N, beside the headline (the driver runs one command per N)
+    plain = not (args.ntaxa or args.patterns or args.ncat)
+    if plain and ((args.workload == "dna" and D.world > 1 and not args.no_also) or args.also):
+        also = []
+        for w in ("dna4", "codon"):
+            if w == args.workload:
+                continue
+            r = run_workload(args, D, pkg, synth, w, max(20, args.steps // 4), max(5, args.warmup // 4), False)
+            r.pop("sustained", None)
+            also.append(r)
+        out["also"] = also
+
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
-    if rank == 0:
+    if D.rank == 0:
         print(json.dumps(out), flush=True)
-    if collective:
-        dist.destroy_process_group()
+    if D.collective:
+        D.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -54,6 +54,12 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
         return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_create: 4-state path supports ncat in {1..8}");
     if (nstates != 4 && ncat > (nstates == 20 ? 96 : 16))  // 20 states: (class, rate) components of mixtures
         return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_create: ncat must be <= 16 (<= 96 components for 20 states)");
+    // the 4-state kernels address a vector slab with a wave-uniform base + one 32-bit per-lane byte offset
+    // (kernels_valu4.hip, voff): a slab of 4 GiB or more would wrap silently, so it is refused here
+    if (nstates == 4 && (uint64_t)round_up(nptn, 64) * (uint64_t)(nstates * ncat) * 8u >= (1ull << 32))
+        return fail(IQHIP_ERR_UNSUPPORTED,
+                    "iqhip_create: nptn * nstates * ncat * 8 must stay below 4 GiB per vector on the 4-state path "
+                    "(shard the patterns over more engines)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(IQHIP_ERR_NO_DEVICE, "iqhip_create: no HIP device available");
@@ -1145,6 +1151,10 @@ extern "C" int iqhip_optimize_branch_batch(iqhip_engine *e, const iqhip_branch_t
                               hipMemcpyHostToDevice, e->stream));
         const unsigned int parity = e->batch_launches & 1u;
         e->batch_launches++;
+        // this launch's arrival counters start at zero whatever the task counts of earlier launches were (a launch
+        // only clears the first m counters of the other parity, so a smaller batch in between leaves the rest dirty)
+        HIPCHK(hipMemsetAsync(e->d_batch_barriers + (size_t)parity * e->batch_cap, 0, sizeof(unsigned int) * (size_t)m,
+                              e->stream));
         HIPCHK(launch_newton_batch(e, e->d_batch_tasks, m, G, e->d_theta_batch, theta_stride, e->d_batch_partials,
                                    e->d_batch_barriers + (size_t)parity * e->batch_cap,
                                    e->d_batch_barriers + (size_t)(1u - parity) * e->batch_cap, e->d_batch_out));

@@ -248,6 +248,48 @@ def make_workload(ntaxa, npatterns, model, seed, missing_frac=0.0, state_unknown
     raise RuntimeError("could not reach the requested number of distinct patterns")
 
 
+# the BASELINE.json workloads (bench.py and tests/test_baseline_shapes_gpu.py build the SAME inputs from here):
+# name -> (ntaxa, patterns, nstates, ncat, seq_type); seq_type as iqhost::SeqType (0 DNA, 1 protein, 2 codon)
+BASELINE_SHAPES = {
+    "dna": (50, 100000, 4, 4, 0),        # configs[1]: DNA 50 taxa x 100k patterns, GTR+G4
+    "protein": (100, 50000, 20, 4, 1),   # configs[2]: protein 100 x 50k, 20-state +G4
+    "dna4": (200, 1000000, 4, 4, 0),     # configs[3]: DNA 200 x 1M, sharded over the GPUs (125k per GPU at N = 8)
+    "codon": (50, 20000, 64, 1, 2),      # configs[4]: codon 64-state 50 x 20k
+    "mixture": (50, 10000, 20, 40, 1),   # C10+G4 shape (10 classes x 4 rates), not a BASELINE config
+}
+
+
+def baseline_model(workload, ncat=0):
+    """The model of a BASELINE workload (and, for mixtures, the class the sites are simulated under)."""
+    T0, P0, nst, C0, seq_type = BASELINE_SHAPES[workload]
+    ncat = ncat or C0
+    if workload == "mixture":
+        model = mixture_model(20, 10, 7, alpha=0.9, ncat=4)
+        return model, model.classes[0]
+    if nst == 4:
+        return gtr_model(rates6=(1.5, 2.4, 1.8, 1.9, 2.8, 1.0), freqs=(0.25, 0.26, 0.25, 0.24), alpha=0.9, ncat=ncat), None
+    # random reversible 20-/64-state model of the LG+G4 / GY shape (the reference's empirical matrices are
+    # constants of its source and are not copied); codon: ncat = 1 as GY+F1X4, stop-codon-like rare states
+    return random_reversible_model(nst, 7, alpha=0.9 if ncat > 1 else None, ncat=ncat, min_freq=1e-4), None
+
+
+def baseline_workload(workload, ntaxa=0, patterns=0, shard=0, ncat=0):
+    """-> (newick, patterns[ntaxa, P] uint8, ptn_freq[P], model).  The tree is the same for every shard
+    (seed 1); shard r simulates its own sites (seed 1000 + r), as one rank of a pattern-sharded run does."""
+    T0, P0, nst, C0, seq_type = BASELINE_SHAPES[workload]
+    T, P = ntaxa or T0, patterns or P0
+    model, sim_model = baseline_model(workload, ncat)
+    nwk = random_tree_newick(T, 1)
+    nsites = int(P * 1.02) + 64
+    while True:
+        st = simulate_alignment(nwk, sim_model or model, nsites, 1000 + shard)
+        pat, freq = compress_patterns(st)
+        if pat.shape[1] >= P:
+            break
+        nsites = int(nsites * 1.3)
+    return nwk, np.ascontiguousarray(pat[:, :P]), freq[:P].copy(), model
+
+
 # -------------------------------------------------------------------------------------------
 # mixture models (ModelMixture: phylokernelmixture.h / phylokernelmixrate.h)
 # -------------------------------------------------------------------------------------------

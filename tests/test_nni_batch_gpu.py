@@ -134,3 +134,44 @@ def test_batch_and_consumer_entry_points_reject_bad_input(pkg, synth, oracle):
     t2.compute_likelihood()
     assert lib.iqhip_pattern_lh_cat(t2.engine, 0.1, dp) != 0 and b"compute_theta" in lib.iqhip_last_error()
     assert lib.iqhip_pattern_lh_cat(t.engine, -1.0, dp) != 0
+
+
+def test_batch_sizes_may_vary_between_calls(pkg, synth, oracle):
+    """10, then 3, then 10 tasks with several workgroups per task (G > 1).  The per-task arrival
+    counters of a launch must start at zero whatever the task counts of the launches before it were; a dirty counter
+    lets workgroups read partial sums their peers have not written yet (silently wrong, timing dependent)."""
+    import ctypes as C
+    lib = pkg.libiqhip()
+
+    class Task(C.Structure):
+        _fields_ = [("ops", C.c_void_p), ("nops", C.c_int32), ("max_steps", C.c_int32), ("a", pkg.BranchEnd), ("b", pkg.BranchEnd),
+                    ("xguess", C.c_double), ("x1", C.c_double), ("x2", C.c_double), ("xacc", C.c_double)]
+
+    class Result(C.Structure):
+        _fields_ = [("optx", C.c_double), ("d2l", C.c_double), ("lnl", C.c_double), ("nsteps", C.c_int32), ("status", C.c_int32)]
+
+    lib.iqhip_optimize_branch_batch.argtypes = [C.c_void_p, C.POINTER(Task), C.c_int, C.POINTER(C.c_double), C.POINTER(Result)]
+    t, ot, *_ = make_case(synth, oracle, pkg, 16, 6000, 4, 4, 9191, mem_mode=pkg.LM_ALL_BRANCH)
+    assert t.nptn > 4 * 256                      # several workgroups per task
+    t.compute_likelihood()
+    t.compute_all_partial_lh()
+    inner = [(x, y) for x in range(t.num_nodes) for y, _ in t.neighbors(x)
+             if x < y and not ot.is_leaf(x) and not ot.is_leaf(y)]
+    assert len(inner) >= 10
+    tasks = [Task(None, 0, 10, pkg.key_end(t.neighbor_info(x, y)["key"]), pkg.key_end(t.neighbor_info(y, x)["key"]),
+                  0.05 + 0.01 * k, 1e-6, 100.0, 1e-6) for k, (x, y) in enumerate(inner[:10])]
+
+    def run(sub):
+        res = (Result * len(sub))()
+        assert lib.iqhip_optimize_branch_batch(t.engine, (Task * len(sub))(*sub), len(sub), None, res) == 0, lib.iqhip_last_error()
+        return [(r.optx, r.d2l, r.lnl, r.nsteps, r.status) for r in res]
+
+    single = [run([k])[0] for k in tasks]        # one task per launch: the branch-by-branch values
+    for _ in range(3):
+        first = run(tasks)
+        small = run(tasks[4:7])
+        third = run(tasks)
+        for got, want in ((first, single), (third, single), (small, single[4:7])):
+            for g, w in zip(got, want):
+                assert g[3:] == w[3:] == (w[3], 0)                      # same step count, status ok
+                np.testing.assert_allclose(g[:3], w[:3], rtol=1e-10)    # optx, d2l, lnl (same grid -> usually bitwise)
