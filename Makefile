@@ -10,7 +10,7 @@ CSRC       := $(PKG)/csrc
 HOST       := $(PKG)/host
 LIBDIR     := $(PKG)/lib
 HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result
-HIP_SRCS   := $(CSRC)/engine.hip $(CSRC)/kernels_valu4.hip $(CSRC)/kernels_mfma.hip $(CSRC)/kernels_newton.hip $(CSRC)/kernels_rell.hip
+HIP_SRCS   := $(CSRC)/engine.hip $(CSRC)/kernels_valu4.hip $(CSRC)/kernels_mfma.hip $(CSRC)/kernels_newton.hip $(CSRC)/kernels_rell.hip $(CSRC)/comm.hip $(CSRC)/sharded.hip
 HIP_OBJS   := $(patsubst $(CSRC)/%.hip,$(LIBDIR)/%.o,$(HIP_SRCS))
 
 all: $(LIBDIR)/libiqhip.so $(LIBDIR)/libiqhost.so $(LIBDIR)/iqhip_lnl oracle/liblh_oracle.so
@@ -22,7 +22,7 @@ $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/iqhip_internal.h include/iqhip.h | $(LIBDIR
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIBDIR)/libiqhip.so: $(HIP_OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS) -ldl
 
 HOST_SRCS  := $(HOST)/phylo_host.cpp $(HOST)/iqhost_c.cpp $(HOST)/model_host.cpp $(HOST)/alignment_host.cpp $(HOST)/iqmodel_c.cpp
 HOST_HDRS  := $(HOST)/phylo_host.h $(HOST)/model_host.h $(HOST)/alignment_host.h include/iqhip.h

@@ -120,10 +120,32 @@ class Dist:
         return float(t.item())
 
 
-def enable_collective(tree, D, lib):
-    """Sharded run: the engine works on torch's current stream and leaves each result vector in a torch-owned device
-    buffer, which is all-reduced over RCCL before the single host read."""
+def enable_collective(tree, D, lib, pkg, mode):
+    """Sharded run, one process per GPU.  mode "rccl" (default): the engine joins an RCCL communicator of its own
+    (iqhip_comm_init_rank; the 128-byte id travels over torch.distributed) and all-reduces every result vector
+    itself, in C++, on its stream.  mode "torch": the older caller-owned collective -- the engine works on torch's
+    current stream and leaves each result vector in a torch-owned device buffer, which a Python hook all-reduces
+    with torch.distributed before the single host read.  If the C++ communicator cannot be made on some rank, ALL
+    ranks fall back to "torch" and the JSON line says so."""
     torch = D.torch
+    if mode == "rccl":
+        ok, err = 1, ""
+        try:
+            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if D.rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
+            D.dist.broadcast(idt, src=0)
+            tree.attach_comm(D.world, D.rank, bytes(idt.cpu().numpy().tobytes()))
+        except Exception as ex:  # noqa: BLE001
+            ok, err = 0, str(ex)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        D.dist.all_reduce(flag, op=D.dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return "rccl: ncclAllReduce inside libiqhip.so (iqhip_comm_init_rank)"
+        if ok:
+            raise SystemExit("C++ communicator made on this rank but not on all: cannot continue consistently")
+        sys.stderr.write("[bench] C++ RCCL communicator failed (%s): falling back to torch.distributed\n" % err)
+        mode = "torch (fallback: %s)" % err
     stream = torch.cuda.current_stream()
     assert lib.iqhip_set_stream(tree.engine, C.c_void_p(stream.cuda_stream)) == 0
     res = torch.zeros(2 + 4096, dtype=torch.float64, device="cuda")
@@ -134,6 +156,7 @@ def enable_collective(tree, D, lib):
         D.dist.all_reduce(res[:n], op=D.dist.ReduceOp.SUM)
     tree._collective_buffer = res
     tree.set_allreduce_hook(hook)
+    return "torch.distributed all_reduce from a Python hook%s" % (mode[5:] if mode.startswith("torch (") else "")
 
 
 def kernel_name(pkg, nst, ncat, nclass):
@@ -167,8 +190,9 @@ def run_workload(args, D, pkg, synth, workload, steps, warmup, with_cpu_baseline
         tree.set_heavy_first(False)
     tree.attach_engine(D.local_rank)
     eng = tree.engine
+    collective = None
     if D.collective:
-        enable_collective(tree, D, lib)
+        collective = enable_collective(tree, D, lib, pkg, args.collective)
 
     def step():  # clearAllPartialLH(); computeLikelihood() on the C++ side of the boundary
         return tree.clear_and_compute_likelihood()
@@ -264,7 +288,8 @@ def run_workload(args, D, pkg, synth, workload, steps, warmup, with_cpu_baseline
                                "full traversal + root-branch lnL" % (workload.upper(), T, P, model.name),
                    "ntaxa": T, "patterns_per_gpu": P, "patterns_total": P * D.world, "nstates": nst,
                    "ncat": model.ncat,
-                   "parallelism": "patterns sharded over %d GPU(s), 1 RCCL all-reduce/step" % D.world},
+                   "parallelism": "patterns sharded over %d GPU(s), 1 RCCL all-reduce/step" % D.world,
+                   "collective": collective},
         "lnL": lnl,
         "host_overhead_ms_per_step": dt / steps * 1e3 - avg_ms.value * lpt,
         "roofline": roof,
@@ -318,6 +343,8 @@ def main():
     ap.add_argument("--also", action="store_true", help="add the 'also' results to a non-default workload / N = 1 run")
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="after the timed K steps, repeat the step for this long (activity evidence; 0 = off)")
+    ap.add_argument("--collective", choices=["rccl", "torch"], default="rccl",
+                    help="N > 1: rccl = the engine's own communicator (C++), torch = torch.distributed from a Python hook")
     ap.add_argument("--force-collective", action="store_true",
                     help="exercise the N>1 path (RCCL all-reduce of the result vector) even with one rank")
     ap.add_argument("--reference-order", action="store_true",

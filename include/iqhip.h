@@ -27,8 +27,14 @@
  *   - host-layout arrays use the reference's layout: partial_lh[ptn*block + c*nstates + i],
  *     evec[x*n+i] = U[x][i], inv_evec[i*n+x] = U^-1[i][x]; the device layout
  *     is private and converted by the fetch/upload calls.
- *   - patterns may be a shard [first, first+nptn) of the alignment: every result of this
- *     ABI is then the shard's partial sum; the caller all-reduces (RCCL) the result vector.
+ *   - patterns shard over GPUs (every pattern is independent; only scalar sums cross).  Two forms,
+ *     both with ONE collective per evaluation -- ncclAllReduce (SUM, f64) over RCCL of the few result doubles:
+ *       one process, several GPUs (what the single-process reference needs): iqhip_create_sharded returns an
+ *         engine that fronts one shard per device; every call below works on it unchanged;
+ *       one process per GPU (MPI / torch.distributed programs): each rank creates its own engine on its pattern
+ *         range and joins a communicator with iqhip_comm_unique_id / iqhip_comm_init_rank; from then on every
+ *         synchronous call all-reduces its result in place on the device before the host reads it, so all ranks
+ *         return identical values.
  */
 #ifndef IQHIP_H_
 #define IQHIP_H_
@@ -40,7 +46,7 @@
 extern "C" {
 #endif
 
-#define IQHIP_ABI_VERSION 1
+#define IQHIP_ABI_VERSION 2
 
 enum {
     IQHIP_OK = 0,
@@ -87,6 +93,30 @@ int iqhip_device_count(void);
 int iqhip_create(iqhip_engine **out, int device, int nstates, int ncat, int64_t nptn,
                  int ntaxa);
 void iqhip_destroy(iqhip_engine *e);
+
+/* ---- pattern sharding over GPUs -------------------------------------------------------------------------------
+ * The reference sums over patterns inside one process (phylokernel.h:251,335,410,592-643,951-962); these calls
+ * are what replaces those sums when the patterns live on several GPUs.
+ *
+ * iqhip_create_sharded: ONE engine handle over ndev GPUs.  Shard g holds the contiguous pattern range
+ * [nptn*g/ndev, nptn*(g+1)/ndev) rounded down to multiples of 64 (iqhip_shard_range) of every vector; the model
+ * tables are replicated.  All other arguments as iqhip_create; the handle is used with every entry point of this
+ * header exactly like a single-device engine (the *_async / result-buffer calls excepted: it reduces itself).
+ * reduce_mode: IQHIP_REDUCE_RCCL -- per evaluation one grouped ncclAllReduce on the shards' streams (devices must
+ * be distinct); IQHIP_REDUCE_HOST -- every shard writes its result doubles to pinned host memory and the host adds
+ * them in shard order (also allows shards that share a device). */
+enum { IQHIP_REDUCE_RCCL = 0, IQHIP_REDUCE_HOST = 1 };
+int iqhip_create_sharded(iqhip_engine **out, const int *device_ids, int ndev, int reduce_mode, int nstates, int ncat,
+                         int64_t nptn, int ntaxa);
+int iqhip_num_shards(iqhip_engine *e); /* 1 for a plain engine */
+int iqhip_shard_range(iqhip_engine *e, int shard, int64_t *first, int64_t *count, int *device);
+/* One process per GPU: rank 0 obtains the 128-byte id (ncclGetUniqueId), the caller distributes it (MPI_Bcast,
+ * torch.distributed, a file), every rank attaches its engine.  nptn of each engine is that rank's pattern count.
+ * Afterwards all ranks must make the same sequence of compute calls (each contains the collective). */
+#define IQHIP_COMM_ID_BYTES 128
+int iqhip_comm_unique_id(void *id_out /* IQHIP_COMM_ID_BYTES */);
+int iqhip_comm_init_rank(iqhip_engine *e, int nranks, int rank, const void *id /* IQHIP_COMM_ID_BYTES */);
+int iqhip_comm_size(iqhip_engine *e); /* ranks / shards that share the patterns; 1 = not sharded */
 
 /* Optional: run on the caller's HIP stream (hipStream_t) instead of the engine's own. */
 int iqhip_set_stream(iqhip_engine *e, void *hip_stream);
@@ -166,7 +196,9 @@ int iqhip_lnl_from_theta(iqhip_engine *e, double len, double *lnl);
  * with the reference's update rule, bracketing and stopping tests (x1/x2 = min/max branch length,
  * xacc = min branch length, max_steps = maxNRStep).  Returns the optimised length (*optx), the last
  * second derivative (*d2l, as minimizeNewton's d2l) and the number of derivative evaluations.
- * Not available on a sharded engine (each step would need an all-reduce): use iqhip_derv there. */
+ * On a sharded engine every derivative evaluation needs the all-reduce of {df, ddf}, so the solve is a chain of
+ * enqueued steps instead of one kernel (derivative kernel -> all-reduce -> 1-thread update kernel that applies the
+ * same rule to device-resident state); the host reads the state once per few steps, not once per step. */
 int iqhip_newton_branch(iqhip_engine *e, double xguess, double x1, double x2, double xacc,
                         int max_steps, double *optx, double *d2l, int *nsteps);
 /* optimizeOneBranch in one submission and one host round trip: the pending node updates of both
@@ -176,7 +208,17 @@ int iqhip_optimize_branch(iqhip_engine *e, const iqhip_node_op *ops, int nops, i
                           iqhip_branch_end b, double xguess, double x1, double x2, double xacc,
                           int max_steps, double *sum_scale, double *optx, double *d2l, int *nsteps);
 
-/* Sharded / asynchronous use.  The *_async forms enqueue the same work but leave the
+/* The same update rule as a host-side state machine (128 opaque bytes), for callers that own the collective: evaluate
+ * {df, ddf} at *first_x / *next_x (iqhip_derv_async + their own all-reduce), feed the sums to _update until *done.
+ * status as iqhip_branch_result.status.  No likelihood arithmetic happens in these three calls. */
+#define IQHIP_NEWTON_STATE_BYTES 128
+int iqhip_newton_host_init(void *state, double xguess, double x1, double x2, double xacc, int max_steps, double *first_x);
+int iqhip_newton_host_update(void *state, double df_sum, double ddf_sum, double *next_x, int *done);
+int iqhip_newton_host_result(const void *state, double *optx, double *d2l, int *nsteps, int *status);
+
+/* Asynchronous use (a caller that owns the collective itself, e.g. a torch.distributed program that all-reduces a
+ * tensor it bound as the result buffer; engines with a communicator and sharded engines do this internally and
+ * refuse these calls).  The *_async forms enqueue the same work but leave the
  * result on the device: `iqhip_result_device_ptr` is a device array of
  * iqhip_result_capacity() doubles laid out as
  *    [0] = lnl or df, [1] = ddf, [2 .. 2+nops) = sum_scale per op
@@ -188,6 +230,8 @@ int iqhip_result_capacity(iqhip_engine *e);
 int iqhip_traverse_lnl_async(iqhip_engine *e, const iqhip_node_op *ops, int nops,
                              iqhip_branch_end a, iqhip_branch_end b, double len);
 int iqhip_derv_async(iqhip_engine *e, double len);
+int iqhip_update_partials_async(iqhip_engine *e, const iqhip_node_op *ops, int nops); /* result[2+k] = sum_scale */
+int iqhip_lnl_from_theta_async(iqhip_engine *e, double len);                          /* result[0] = lnl */
 int iqhip_result_read(iqhip_engine *e, double *out, int ndoubles); /* syncs the stream */
 int iqhip_synchronize(iqhip_engine *e);
 
@@ -203,7 +247,8 @@ int iqhip_fetch_theta(iqhip_engine *e, double *out /* nptn*block, ref layout */)
  * read any existing vector, must write vectors no other task touches -- the nni_partial_lh scratch buffers,
  * phylotree.cpp:2901-2924), then optimises the length of branch (a, b) as iqhip_optimize_branch does and
  * evaluates computeLikelihoodFromBuffer at the optimum.  results[t].lnl excludes the lh_scale_factor terms;
- * sum_scale receives the per-op values of all tasks, concatenated in task order.  +ASC is not supported. */
+ * sum_scale receives the per-op values of all tasks, concatenated in task order.  +ASC is not supported.
+ * On a sharded engine the tasks run one after the other (every Newton step needs its own all-reduce). */
 typedef struct iqhip_branch_task {
     const iqhip_node_op *ops;
     int32_t nops;

@@ -31,6 +31,9 @@ IQHIP_SYMBOLS = [
     "iqhip_fetch_theta", "iqhip_upload_partial", "iqhip_timing_enable", "iqhip_timing_read",
     "iqhip_fetch_pattern_lh_scaled", "iqhip_set_boot_samples", "iqhip_rell", "iqhip_rell_async",
     "iqhip_set_mixture_model", "iqhip_pattern_lh_cat", "iqhip_optimize_branch_batch",
+    "iqhip_create_sharded", "iqhip_num_shards", "iqhip_shard_range", "iqhip_comm_unique_id", "iqhip_comm_init_rank",
+    "iqhip_comm_size", "iqhip_update_partials_async", "iqhip_lnl_from_theta_async",
+    "iqhip_newton_host_init", "iqhip_newton_host_update", "iqhip_newton_host_result",
 ]
 
 
@@ -122,6 +125,18 @@ def libiqhip():
     lib.iqhip_set_boot_samples.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     lib.iqhip_rell.argtypes = [vp, BranchEnd, BranchEnd, dp]
     lib.iqhip_rell_async.argtypes = [vp, BranchEnd, BranchEnd]
+    lib.iqhip_create_sharded.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                         C.c_int]
+    lib.iqhip_num_shards.argtypes = [vp]
+    lib.iqhip_shard_range.argtypes = [vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+    lib.iqhip_comm_unique_id.argtypes = [vp]
+    lib.iqhip_comm_init_rank.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.iqhip_comm_size.argtypes = [vp]
+    lib.iqhip_update_partials_async.argtypes = [vp, C.POINTER(NodeOp), C.c_int]
+    lib.iqhip_lnl_from_theta_async.argtypes = [vp, C.c_double]
+    lib.iqhip_newton_host_init.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, dp]
+    lib.iqhip_newton_host_update.argtypes = [vp, C.c_double, C.c_double, dp, C.POINTER(C.c_int)]
+    lib.iqhip_newton_host_result.argtypes = [vp, dp, dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.iqhip_timing_enable.argtypes = [vp, C.c_int]
     lib.iqhip_timing_read.argtypes = [vp, dp, C.POINTER(C.c_int64), C.c_int]
     lib._iq_typed = True
@@ -147,6 +162,8 @@ def libiqhost():
     lib.iqhost_set_mem_mode.argtypes = [vp, C.c_int]
     lib.iqhost_set_kernel.argtypes = [vp, C.c_int]
     lib.iqhost_attach_engine.argtypes = [vp, C.c_int]
+    lib.iqhost_attach_engine_sharded.argtypes = [vp, C.POINTER(C.c_int), C.c_int, C.c_int]
+    lib.iqhost_attach_comm.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
     lib.iqhost_set_dry_run.argtypes = [vp, C.c_int]
     lib.iqhost_set_heavy_first.argtypes = [vp, C.c_int]
     lib.iqhost_set_device_newton.argtypes = [vp, C.c_int]
@@ -232,6 +249,40 @@ class HostError(RuntimeError):
 
 
 LK_EIGEN, LK_EIGEN_SSE, LK_EIGEN_HIP = 0, 1, 2
+REDUCE_RCCL, REDUCE_HOST = 0, 1
+
+
+class NewtonStateMachine:
+    """Optimization::minimizeNewton as the engine's step-at-a-time state machine (iqhip_newton_host_*)."""
+
+    def __init__(self, xguess, x1, x2, xacc, max_steps):
+        self.lib = libiqhip()
+        self.buf = C.create_string_buffer(128)
+        x = C.c_double()
+        if self.lib.iqhip_newton_host_init(self.buf, xguess, x1, x2, xacc, max_steps, C.byref(x)) != 0:
+            raise HostError(self.lib.iqhip_last_error().decode())
+        self.x, self.done = x.value, False
+
+    def update(self, df_sum, ddf_sum):
+        x, d = C.c_double(), C.c_int()
+        self.lib.iqhip_newton_host_update(self.buf, df_sum, ddf_sum, C.byref(x), C.byref(d))
+        self.x, self.done = x.value, bool(d.value)
+        return self.x
+
+    def result(self):
+        optx, d2l, n, st = C.c_double(), C.c_double(), C.c_int(), C.c_int()
+        if self.lib.iqhip_newton_host_result(self.buf, C.byref(optx), C.byref(d2l), C.byref(n), C.byref(st)) != 0:
+            raise HostError(self.lib.iqhip_last_error().decode())
+        return optx.value, d2l.value, n.value, st.value
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the engine library (rank 0; broadcast the 128 bytes to the other ranks)."""
+    lib = libiqhip()
+    buf = C.create_string_buffer(128)
+    if lib.iqhip_comm_unique_id(buf) != 0:
+        raise HostError(lib.iqhip_last_error().decode())
+    return buf.raw
 LM_PER_NODE, LM_ALL_BRANCH = 0, 1
 SEQ_DNA, SEQ_PROTEIN, SEQ_CODON, SEQ_OTHER = 0, 1, 2, 3
 
@@ -314,6 +365,17 @@ class PhyloTree:
 
     def attach_engine(self, device=0):
         self._chk(self.lib.iqhost_attach_engine(self.h, device))
+
+    def attach_engine_sharded(self, devices, reduce_mode=REDUCE_RCCL):
+        """one engine handle over several GPUs of this process (iqhip_create_sharded)"""
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self._chk(self.lib.iqhost_attach_engine_sharded(self.h, arr, len(devices), int(reduce_mode)))
+
+    def attach_comm(self, nranks, rank, unique_id):
+        """one process per GPU: join this tree's engine to the other ranks' (iqhip_comm_init_rank);
+        unique_id = the 128 bytes rank 0 got from comm_unique_id(), distributed by the caller"""
+        assert len(unique_id) == 128
+        self._chk(self.lib.iqhost_attach_comm(self.h, int(nranks), int(rank), bytes(unique_id)))
 
     def set_device_newton(self, on=True):
         self._chk(self.lib.iqhost_set_device_newton(self.h, int(on)))

@@ -14,10 +14,13 @@
 using namespace iqhip;
 
 static thread_local std::string g_err;
-static int fail(int code, const std::string &msg) {
+namespace iqhip {
+int set_error(int code, const std::string &msg) {
     g_err = msg;
     return code;
 }
+}  // namespace iqhip
+static int fail(int code, const std::string &msg) { return set_error(code, msg); }
 #define HIPCHK(call)                                                                  \
     do {                                                                              \
         hipError_t _s = (call);                                                       \
@@ -161,7 +164,17 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
 
 extern "C" void iqhip_destroy(iqhip_engine *e) {
     if (!e) return;
+    if (!e->shards.empty()) {
+        sharded::destroy(e);
+        delete e;
+        return;
+    }
     hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    comm_destroy(e);
+    if (e->d_result_dev) hipFree(e->d_result_dev);
+    if (e->d_nstate) hipFree(e->d_nstate);
+    if (e->h_nstate) hipHostFree(e->h_nstate);
     if (e->stream) hipStreamSynchronize(e->stream);
     for (auto &s : e->slabs) {
         if (s.plh) hipFree(s.plh);
@@ -186,6 +199,7 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
 
 extern "C" int iqhip_set_stream(iqhip_engine *e, void *hip_stream) {
     if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    if (!e->shards.empty()) return fail(IQHIP_ERR_UNSUPPORTED, "a sharded engine runs on its shards' own streams");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->own_stream) hipStreamDestroy(e->stream);
@@ -234,6 +248,7 @@ static int slab_for_key(iqhip_engine *e, uint64_t key, bool create, int *idx) {
 
 extern "C" int iqhip_reserve(iqhip_engine *e, int nvectors) {
     if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    if (!e->shards.empty()) return sharded::reserve(e, nvectors);
     HIPCHK(hipSetDevice(e->device));
     int have = (int)e->slabs.size();
     for (int i = have; i < nvectors; i++) {
@@ -251,6 +266,7 @@ extern "C" int iqhip_reserve(iqhip_engine *e, int nvectors) {
 
 extern "C" int iqhip_release(iqhip_engine *e, uint64_t key) {
     if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    if (!e->shards.empty()) return sharded::release(e, key);
     auto it = e->key2slab.find(key);
     if (it == e->key2slab.end()) return IQHIP_OK;
     e->free_slabs.push_back(it->second);
@@ -261,6 +277,7 @@ extern "C" int iqhip_release(iqhip_engine *e, uint64_t key) {
 
 extern "C" int iqhip_rekey(iqhip_engine *e, uint64_t old_key, uint64_t new_key) {
     if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    if (!e->shards.empty()) return sharded::rekey(e, old_key, new_key);
     auto it = e->key2slab.find(old_key);
     if (it == e->key2slab.end()) return fail(IQHIP_ERR_INVALID, "iqhip_rekey: unknown key");
     if (old_key == new_key) return IQHIP_OK;
@@ -277,6 +294,7 @@ extern "C" int iqhip_rekey(iqhip_engine *e, uint64_t old_key, uint64_t new_key) 
 // ---------------------------------------------------------------------------------------
 extern "C" int iqhip_set_ptn_freq(iqhip_engine *e, const double *ptn_freq) {
     if (!e || !ptn_freq) return fail(IQHIP_ERR_INVALID, "null argument");
+    if (!e->shards.empty()) return sharded::set_ptn_array(e, ptn_freq, false);
     HIPCHK(hipSetDevice(e->device));
     std::vector<double> tmp((size_t)e->nptn_pad, 0.0);
     memcpy(tmp.data(), ptn_freq, sizeof(double) * (size_t)e->nptn);
@@ -288,6 +306,7 @@ extern "C" int iqhip_set_ptn_freq(iqhip_engine *e, const double *ptn_freq) {
 
 extern "C" int iqhip_set_ptn_invar(iqhip_engine *e, const double *ptn_invar) {
     if (!e || !ptn_invar) return fail(IQHIP_ERR_INVALID, "null argument");
+    if (!e->shards.empty()) return sharded::set_ptn_array(e, ptn_invar, true);
     HIPCHK(hipSetDevice(e->device));
     std::vector<double> tmp((size_t)e->nptn_pad, 0.0);
     memcpy(tmp.data(), ptn_invar, sizeof(double) * (size_t)e->nptn);
@@ -300,6 +319,7 @@ extern "C" int iqhip_set_ptn_invar(iqhip_engine *e, const double *ptn_invar) {
 extern "C" int iqhip_set_alignment(iqhip_engine *e, const uint8_t *states, const double *ptn_freq,
                                    const double *ptn_invar) {
     if (!e || !states || !ptn_freq || !ptn_invar) return fail(IQHIP_ERR_INVALID, "null argument");
+    if (!e->shards.empty()) return sharded::set_alignment(e, states, ptn_freq, ptn_invar);
     if (!e->model_set)
         return fail(IQHIP_ERR_INVALID,
                     "iqhip_set_alignment: call iqhip_set_model first (needs state_unknown)");
@@ -327,6 +347,8 @@ extern "C" int iqhip_set_ascertainment(iqhip_engine *e, int64_t n_unobserved, do
     if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
     if (n_unobserved < 0 || n_unobserved >= e->nptn || (n_unobserved > 0 && !(nsites > 0.0)))
         return fail(IQHIP_ERR_INVALID, "iqhip_set_ascertainment: bad pattern count / site count");
+    if (n_unobserved > 0 && (e->comm || !e->shards.empty()))
+        return fail(IQHIP_ERR_UNSUPPORTED, "+ASC corrections are applied on the host: not available on a sharded engine");
     e->n_unobs = n_unobserved;
     e->asc_nsites = nsites;
     e->pattern_lh_shift = 0.0;
@@ -338,6 +360,8 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
                             int state_unknown, const double *tip /* [state][class][n] */) {
     if (!e || !eval || !evec || !inv_evec || !rates || !props || !tip)
         return fail(IQHIP_ERR_INVALID, "null argument");
+    if (!e->shards.empty())
+        return sharded::set_model(e, nclass, cat_class, eval, evec, inv_evec, rates, props, state_unknown, tip);
     if (state_unknown < e->n || state_unknown > (e->mfma ? 255 : 31))
         return fail(IQHIP_ERR_INVALID, "iqhip_set_model: state_unknown out of range");
     if (e->aln_set && state_unknown != e->state_unknown)
@@ -929,10 +953,33 @@ static int asc_finish_lnl(iqhip_engine *e, double *lnl) {
     return IQHIP_OK;
 }
 
+namespace iqhip {
+int eng_read_result(iqhip_engine *e, int ndoubles) { return read_result(e, ndoubles); }
+int eng_repair_lnl(iqhip_engine *e, double *lnl) { return repair_lnl(e, lnl); }
+}  // namespace iqhip
+
+// Sharded engines (comm.hip): a non-finite lnL is repaired rank by rank (each rank fixes its own _pattern_lh and
+// re-sums its share), then the shares are all-reduced again.  Every rank sees the same all-reduced value, so every
+// rank takes this branch together.
+static int repair_lnl_comm(iqhip_engine *e, double *lnl) {
+    int rc = repair_lnl(e, lnl);
+    if (rc || !e->comm) return rc;
+    HIPCHK(hipMemcpyAsync(e->d_result, lnl, sizeof(double), hipMemcpyHostToDevice, e->stream));
+    rc = comm_allreduce(e, 1);
+    if (rc) return rc;
+    rc = read_result(e, 1);
+    if (rc) return rc;
+    *lnl = e->h_result[0];
+    return IQHIP_OK;
+}
+
 extern "C" int iqhip_update_partials(iqhip_engine *e, const iqhip_node_op *ops, int nops,
                                      double *sum_scale) {
     iqhip_branch_end none = {0, -1, 0};
+    if (e && !e->shards.empty()) return sharded::traverse(e, ops, nops, false, none, none, 0.0, sum_scale, nullptr);
     int rc = submit_traverse(e, ops, nops, false, none, none, 0.0);
+    if (rc) return rc;
+    rc = comm_allreduce(e, 2 + nops);
     if (rc) return rc;
     rc = read_result(e, 2 + nops);
     if (rc) return rc;
@@ -944,7 +991,10 @@ extern "C" int iqhip_update_partials(iqhip_engine *e, const iqhip_node_op *ops, 
 extern "C" int iqhip_traverse_lnl(iqhip_engine *e, const iqhip_node_op *ops, int nops,
                                   iqhip_branch_end a, iqhip_branch_end b, double len,
                                   double *sum_scale, double *lnl) {
+    if (e && !e->shards.empty()) return sharded::traverse(e, ops, nops, true, a, b, len, sum_scale, lnl);
     int rc = submit_traverse(e, ops, nops, true, a, b, len);
+    if (rc) return rc;
+    rc = comm_allreduce(e, 2 + nops);
     if (rc) return rc;
     rc = read_result(e, 2 + nops);
     if (rc) return rc;
@@ -952,7 +1002,7 @@ extern "C" int iqhip_traverse_lnl(iqhip_engine *e, const iqhip_node_op *ops, int
         for (int k = 0; k < nops; k++) sum_scale[k] = e->h_result[2 + k];
     double v = e->h_result[0];
     if (isnan(v) || isinf(v)) {
-        rc = repair_lnl(e, &v);
+        rc = repair_lnl_comm(e, &v);
         if (rc) return rc;
     }
     rc = asc_finish_lnl(e, &v);
@@ -968,12 +1018,22 @@ extern "C" int iqhip_branch_lnl(iqhip_engine *e, iqhip_branch_end a, iqhip_branc
 
 extern "C" int iqhip_traverse_lnl_async(iqhip_engine *e, const iqhip_node_op *ops, int nops,
                                         iqhip_branch_end a, iqhip_branch_end b, double len) {
+    if (e && !e->shards.empty())
+        return fail(IQHIP_ERR_UNSUPPORTED, "a sharded engine reduces its results itself: use the synchronous calls");
     if (e && e->n_unobs > 0)
         return fail(IQHIP_ERR_UNSUPPORTED, "+ASC needs the synchronous calls (its correction is applied on the host)");
     return submit_traverse(e, ops, nops, true, a, b, len);
 }
 
+extern "C" int iqhip_update_partials_async(iqhip_engine *e, const iqhip_node_op *ops, int nops) {
+    if (e && !e->shards.empty())
+        return fail(IQHIP_ERR_UNSUPPORTED, "a sharded engine reduces its results itself: use the synchronous calls");
+    iqhip_branch_end none = {0, -1, 0};
+    return submit_traverse(e, ops, nops, false, none, none, 0.0);
+}
+
 extern "C" int iqhip_compute_theta(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b) {
+    if (e && !e->shards.empty()) return sharded::compute_theta(e, a, b);
     int rc = check_ready(e);
     if (rc) return rc;
     DevBranch br;
@@ -988,6 +1048,8 @@ extern "C" int iqhip_compute_theta(iqhip_engine *e, iqhip_branch_end a, iqhip_br
 }
 
 extern "C" int iqhip_derv_async(iqhip_engine *e, double len) {
+    if (e && !e->shards.empty())
+        return fail(IQHIP_ERR_UNSUPPORTED, "a sharded engine reduces its results itself: use the synchronous calls");
     int rc = check_ready(e);
     if (rc) return rc;
     if (!e->theta_valid) return fail(IQHIP_ERR_INVALID, "iqhip_derv: theta not computed");
@@ -1003,7 +1065,10 @@ extern "C" int iqhip_derv_async(iqhip_engine *e, double len) {
 }
 
 extern "C" int iqhip_derv(iqhip_engine *e, double len, double *df, double *ddf) {
+    if (e && !e->shards.empty()) return sharded::derv(e, len, df, ddf);
     int rc = iqhip_derv_async(e, len);
+    if (rc) return rc;
+    rc = comm_allreduce(e, 2);
     if (rc) return rc;
     rc = read_result(e, e->n_unobs > 0 ? 5 : 2);
     if (rc) return rc;
@@ -1020,21 +1085,171 @@ extern "C" int iqhip_derv(iqhip_engine *e, double len, double *df, double *ddf) 
     return IQHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Newton as a chain of enqueued steps (kernels_newton.hip, "state machine" kernels): the form a sharded engine
+// uses -- every derivative evaluation is followed by an in-stream all-reduce of {df, ddf}, so the loop cannot live
+// in one kernel -- and the fallback when k_newton's grid barrier cannot be trusted.  Steps are enqueued in chunks;
+// the host reads the 128-byte state once per chunk; steps enqueued after convergence do nothing.
+// ---------------------------------------------------------------------------------------
+namespace iqhip {
+int newton_state_alloc(iqhip_engine *e) {
+    if (e->d_nstate) return IQHIP_OK;
+    if (hipMalloc((void **)&e->d_nstate, sizeof(NewtonState)) != hipSuccess ||
+        hipHostMalloc((void **)&e->h_nstate, sizeof(NewtonState)) != hipSuccess)
+        return set_error(IQHIP_ERR_NOMEM, "Newton state");
+    return IQHIP_OK;
+}
+
+// enqueue `nsteps` evaluations + updates on the engine's stream (with the engine's own all-reduce in between)
+int newton_chain_enqueue(iqhip_engine *e, int nsteps) {
+    const int nwaves = (int)e->ntiles;
+    for (int k = 0; k < nsteps; k++) {
+        if (launch_derv_at_state(e, nwaves) != hipSuccess || launch_reduce(e, 0, 2, nwaves) != hipSuccess)
+            return set_error(IQHIP_ERR_HIP, "Newton chain: launch failed");
+        int rc = comm_allreduce(e, 2);
+        if (rc) return rc;
+        if (launch_newton_state_update(e) != hipSuccess) return set_error(IQHIP_ERR_HIP, "Newton chain: launch failed");
+    }
+    return IQHIP_OK;
+}
+
+// the same pieces one at a time, for the single-process front, which interleaves its shards' steps with one grouped
+// all-reduce per step
+int eng_newton_begin(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    if (!e->theta_valid) return set_error(IQHIP_ERR_INVALID, "Newton: theta not computed");
+    rc = newton_state_alloc(e);
+    if (rc) return rc;
+    rc = ensure_slab_rows(e, 2);
+    if (rc) return rc;
+    if (launch_newton_state_init(e, xguess, x1, x2, xacc, max_steps) != hipSuccess)
+        return set_error(IQHIP_ERR_HIP, "Newton chain: launch failed");
+    return IQHIP_OK;
+}
+int eng_newton_eval_enqueue(iqhip_engine *e) {
+    if (hipSetDevice(e->device) != hipSuccess) return set_error(IQHIP_ERR_HIP, "hipSetDevice");
+    const int nwaves = (int)e->ntiles;
+    if (launch_derv_at_state(e, nwaves) != hipSuccess || launch_reduce(e, 0, 2, nwaves) != hipSuccess)
+        return set_error(IQHIP_ERR_HIP, "Newton chain: launch failed");
+    return IQHIP_OK;
+}
+int eng_newton_update_enqueue(iqhip_engine *e) {
+    if (hipSetDevice(e->device) != hipSuccess) return set_error(IQHIP_ERR_HIP, "hipSetDevice");
+    if (launch_newton_state_update(e) != hipSuccess) return set_error(IQHIP_ERR_HIP, "Newton chain: launch failed");
+    return IQHIP_OK;
+}
+
+int newton_state_read(iqhip_engine *e) {
+    if (hipSetDevice(e->device) != hipSuccess) return set_error(IQHIP_ERR_HIP, "hipSetDevice");
+    if (hipMemcpyAsync(e->h_nstate, e->d_nstate, sizeof(NewtonState), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess)
+        return set_error(IQHIP_ERR_HIP, "Newton chain: state read failed");
+    e->staging_busy = false;
+    return IQHIP_OK;
+}
+}  // namespace iqhip
+
+// The state machine on the host, for callers that own the collective themselves (they evaluate {df, ddf} with
+// iqhip_derv_async, all-reduce them their own way and need the reference's update rule between evaluations) and for
+// the CPU tests, which check it step by step against the loop form of optimization.cpp:388-465.
+extern "C" int iqhip_newton_host_init(void *state, double xguess, double x1, double x2, double xacc, int max_steps,
+                                      double *first_x) {
+    if (!state) return fail(IQHIP_ERR_INVALID, "null argument");
+    if (!(x1 >= 0.0) || !(x2 > x1) || !(xacc > 0.0) || max_steps < 1 || !(xguess >= 0.0))
+        return fail(IQHIP_ERR_INVALID, "iqhip_newton_host_init: bad bounds / tolerance / step count");
+    static_assert(sizeof(NewtonState) == IQHIP_NEWTON_STATE_BYTES, "NewtonState size");
+    NewtonState st;
+    newton_init(st, xguess, x1, x2, xacc, max_steps);
+    memcpy(state, &st, sizeof st);
+    if (first_x) *first_x = st.rts;
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_newton_host_update(void *state, double df_sum, double ddf_sum, double *next_x, int *done) {
+    if (!state) return fail(IQHIP_ERR_INVALID, "null argument");
+    NewtonState st;
+    memcpy(&st, state, sizeof st);
+    newton_update(st, df_sum, ddf_sum);
+    memcpy(state, &st, sizeof st);
+    if (next_x) *next_x = st.rts;
+    if (done) *done = st.done;
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_newton_host_result(const void *state, double *optx, double *d2l, int *nsteps, int *status) {
+    if (!state) return fail(IQHIP_ERR_INVALID, "null argument");
+    NewtonState st;
+    memcpy(&st, state, sizeof st);
+    if (!st.done) return fail(IQHIP_ERR_INVALID, "Newton state machine has not finished");
+    if (optx) *optx = st.result;
+    if (d2l) *d2l = st.d2l;
+    if (nsteps) *nsteps = st.neval;
+    if (status) *status = st.status;
+    return IQHIP_OK;
+}
+
+// theta must be resident; result[2..] untouched
+static int newton_chain(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps,
+                        double *optx, double *d2l, int *nsteps) {
+    int rc = newton_state_alloc(e);
+    if (rc) return rc;
+    rc = ensure_slab_rows(e, 2);
+    if (rc) return rc;
+    HIPCHK(launch_newton_state_init(e, xguess, x1, x2, xacc, max_steps));
+    // a typical solve converges in 3..5 evaluations: enqueue that many before looking
+    int enq = 0;
+    for (;;) {
+        const int chunk = enq == 0 ? std::min(4, max_steps + 1) : 2;
+        rc = newton_chain_enqueue(e, chunk);
+        if (rc) return rc;
+        enq += chunk;
+        rc = newton_state_read(e);
+        if (rc) return rc;
+        if (e->h_nstate->done) break;
+        if (enq > max_steps + 2) return fail(IQHIP_ERR_INVALID, "Newton chain did not terminate");
+    }
+    const NewtonState &st = *e->h_nstate;
+    if (st.status == 2) return fail(IQHIP_ERR_INVALID, "Wrong computeFuncDerv (non-finite derivative)");
+    if (st.status == 3) return fail(IQHIP_ERR_INVALID, "Maximum number of iterations exceeded in minimizeNewton");
+    if (optx) *optx = st.result;
+    if (d2l) *d2l = st.d2l;
+    if (nsteps) *nsteps = st.neval;
+    return IQHIP_OK;
+}
+
+// k_newton's grid barrier needs every workgroup resident; a single workgroup needs no barrier.  IQHIP_NEWTON=chain
+// forces the chain form (tests).
+static bool newton_use_chain(const iqhip_engine *e) {
+    if (e->comm) return true;
+    static const bool forced = [] { const char *v = getenv("IQHIP_NEWTON"); return v && !strcmp(v, "chain"); }();
+    return forced;
+}
+
 extern "C" int iqhip_newton_branch(iqhip_engine *e, double xguess, double x1, double x2, double xacc,
                                    int max_steps, double *optx, double *d2l, int *nsteps) {
+    if (!(x1 >= 0.0) || !(x2 > x1) || !(xacc > 0.0) || max_steps < 1 || !(xguess >= 0.0))
+        return fail(IQHIP_ERR_INVALID, "iqhip_newton_branch: bad bounds / tolerance / step count");
+    if (e && !e->shards.empty()) {
+        iqhip_branch_end none = {0, -1, 0};
+        return sharded::optimize_branch(e, nullptr, 0, false, none, none, xguess, x1, x2, xacc, max_steps, nullptr, optx,
+                                        d2l, nsteps);
+    }
     int rc = check_ready(e);
     if (rc) return rc;
     if (!e->theta_valid) return fail(IQHIP_ERR_INVALID, "iqhip_newton_branch: theta not computed");
     if (e->n_unobs > 0) return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_newton_branch: +ASC uses iqhip_derv");
-    if (!(x1 >= 0.0) || !(x2 > x1) || !(xacc > 0.0) || max_steps < 1 || !(xguess >= 0.0))
-        return fail(IQHIP_ERR_INVALID, "iqhip_newton_branch: bad bounds / tolerance / step count");
+    if (newton_use_chain(e)) return newton_chain(e, xguess, x1, x2, xacc, max_steps, optx, d2l, nsteps);
     HIPCHK(launch_newton(e, xguess, x1, x2, xacc, max_steps, e->d_result));
     rc = read_result(e, 4);
     if (rc) return rc;
     const int status = (int)e->h_result[3];
     if (status == 2) return fail(IQHIP_ERR_INVALID, "Wrong computeFuncDerv (non-finite derivative)");
     if (status == 3) return fail(IQHIP_ERR_INVALID, "Maximum number of iterations exceeded in minimizeNewton");
-    if (status == 4) return fail(IQHIP_ERR_HIP, "iqhip_newton_branch: grid barrier timed out");
+    if (status == 4) {  // the grid barrier gave up (another kernel held the CUs): the chain needs no barrier
+        (void)hipStreamSynchronize(e->stream);
+        return newton_chain(e, xguess, x1, x2, xacc, max_steps, optx, d2l, nsteps);
+    }
     if (optx) *optx = e->h_result[0];
     if (d2l) *d2l = e->h_result[1];
     if (nsteps) *nsteps = (int)e->h_result[2];
@@ -1046,9 +1261,22 @@ extern "C" int iqhip_optimize_branch(iqhip_engine *e, const iqhip_node_op *ops, 
                                      int max_steps, double *sum_scale, double *optx, double *d2l, int *nsteps) {
     if (!(x1 >= 0.0) || !(x2 > x1) || !(xacc > 0.0) || max_steps < 1 || !(xguess >= 0.0))
         return fail(IQHIP_ERR_INVALID, "iqhip_optimize_branch: bad bounds / tolerance / step count");
+    if (e && !e->shards.empty())
+        return sharded::optimize_branch(e, ops, nops, true, a, b, xguess, x1, x2, xacc, max_steps, sum_scale, optx, d2l,
+                                        nsteps);
     if (e && e->n_unobs > 0) return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_optimize_branch: +ASC uses iqhip_derv");
     iqhip_branch_end none = {0, -1, 0};
     int rc = IQHIP_OK;
+    if (e && newton_use_chain(e)) {
+        // sharded rank: node updates (their sum_scale rows all-reduced), theta, then the enqueued Newton chain
+        if (nops > 0) {
+            rc = iqhip_update_partials(e, ops, nops, sum_scale);
+            if (rc) return rc;
+        }
+        rc = iqhip_compute_theta(e, a, b);
+        if (rc) return rc;
+        return newton_chain(e, xguess, x1, x2, xacc, max_steps, optx, d2l, nsteps);
+    }
     // two launches per branch: the pending node updates, then one kernel that sums their sum_scale rows,
     // builds theta during its first derivative evaluation and runs the whole Newton-Raphson loop
     if (nops > 0) rc = submit_traverse(e, ops, nops, false, none, none, 0.0, /*skip_reduce=*/true);
@@ -1071,18 +1299,44 @@ extern "C" int iqhip_optimize_branch(iqhip_engine *e, const iqhip_node_op *ops, 
     const int status = (int)r[3];
     if (status == 2) return fail(IQHIP_ERR_INVALID, "Wrong computeFuncDerv (non-finite derivative)");
     if (status == 3) return fail(IQHIP_ERR_INVALID, "Maximum number of iterations exceeded in minimizeNewton");
-    if (status == 4) return fail(IQHIP_ERR_HIP, "iqhip_optimize_branch: grid barrier timed out");
+    if (status == 4) {  // grid barrier gave up: theta was built by the first evaluation, finish with the chain
+        (void)hipStreamSynchronize(e->stream);
+        return newton_chain(e, xguess, x1, x2, xacc, max_steps, optx, d2l, nsteps);
+    }
     if (optx) *optx = r[0];
     if (d2l) *d2l = r[1];
     if (nsteps) *nsteps = (int)r[2];
     return IQHIP_OK;
 }
 
+// iqhip_optimize_branch_batch on a sharded engine (a rank with a communicator, or the single-process front): the
+// tasks run one after the other through the chain form -- every Newton step of every task needs its own all-reduce,
+// so nothing is gained by putting them side by side in one kernel; what stays is one C call per batch.
+static int optimize_branch_batch_sequential(iqhip_engine *e, const iqhip_branch_task *tasks, int ntasks,
+                                            double *sum_scale, iqhip_branch_result *results) {
+    size_t off = 0;
+    for (int t = 0; t < ntasks; t++) {
+        const iqhip_branch_task &k = tasks[t];
+        if (k.nops < 0 || (k.nops > 0 && !k.ops)) return fail(IQHIP_ERR_INVALID, "bad ops array in a task");
+        iqhip_branch_result &r = results[t];
+        r.status = 0;
+        int rc = iqhip_optimize_branch(e, k.ops, k.nops, k.a, k.b, k.xguess, k.x1, k.x2, k.xacc, k.max_steps,
+                                       sum_scale ? sum_scale + off : nullptr, &r.optx, &r.d2l, &r.nsteps);
+        if (rc) return rc;
+        rc = iqhip_lnl_from_theta(e, r.optx, &r.lnl);
+        if (rc) return rc;
+        off += (size_t)k.nops;
+    }
+    return IQHIP_OK;
+}
+
 extern "C" int iqhip_optimize_branch_batch(iqhip_engine *e, const iqhip_branch_task *tasks, int ntasks,
                                            double *sum_scale, iqhip_branch_result *results) {
+    if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    if (!tasks || !results || ntasks < 1) return fail(IQHIP_ERR_INVALID, "bad task array");
+    if (!e->shards.empty() || e->comm) return optimize_branch_batch_sequential(e, tasks, ntasks, sum_scale, results);
     int rc = check_ready(e);
     if (rc) return rc;
-    if (!tasks || !results || ntasks < 1) return fail(IQHIP_ERR_INVALID, "bad task array");
     if (e->n_unobs > 0) return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_optimize_branch_batch: +ASC is not supported");
     std::vector<iqhip_node_op> all;
     std::vector<int> segs(ntasks);
@@ -1181,7 +1435,9 @@ extern "C" int iqhip_optimize_branch_batch(iqhip_engine *e, const iqhip_branch_t
     return IQHIP_OK;
 }
 
-extern "C" int iqhip_lnl_from_theta(iqhip_engine *e, double len, double *lnl) {
+extern "C" int iqhip_lnl_from_theta_async(iqhip_engine *e, double len) {
+    if (e && !e->shards.empty())
+        return fail(IQHIP_ERR_UNSUPPORTED, "a sharded engine reduces its results itself: use the synchronous calls");
     int rc = check_ready(e);
     if (rc) return rc;
     if (!e->theta_valid) return fail(IQHIP_ERR_INVALID, "iqhip_lnl_from_theta: theta not computed");
@@ -1192,11 +1448,20 @@ extern "C" int iqhip_lnl_from_theta(iqhip_engine *e, double len, double *lnl) {
     if (e->mfma) HIPCHK(launch_stream_mfma(e, 3, nullptr, len, nwaves));
     else HIPCHK(launch_lnl_theta4(e, len, nwaves));
     HIPCHK(launch_reduce(e, 0, 2, nwaves));
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_lnl_from_theta(iqhip_engine *e, double len, double *lnl) {
+    if (e && !e->shards.empty()) return sharded::lnl_from_theta(e, len, lnl);
+    int rc = iqhip_lnl_from_theta_async(e, len);
+    if (rc) return rc;
+    rc = comm_allreduce(e, 1);
+    if (rc) return rc;
     rc = read_result(e, 2);
     if (rc) return rc;
     double v = e->h_result[0];
     if (isnan(v) || isinf(v)) {
-        rc = repair_lnl(e, &v);
+        rc = repair_lnl_comm(e, &v);
         if (rc) return rc;
     }
     rc = asc_finish_lnl(e, &v);
@@ -1210,6 +1475,8 @@ extern "C" int iqhip_lnl_from_theta(iqhip_engine *e, double len, double *lnl) {
 // ---------------------------------------------------------------------------------------
 extern "C" int iqhip_bind_result_buffer(iqhip_engine *e, void *device_ptr, int capacity_doubles) {
     if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    if (!e->shards.empty() || e->comm)
+        return fail(IQHIP_ERR_UNSUPPORTED, "an engine with a communicator reduces in its own device result vector");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (!device_ptr) {
@@ -1222,10 +1489,12 @@ extern "C" int iqhip_bind_result_buffer(iqhip_engine *e, void *device_ptr, int c
     e->result_cap = std::min(capacity_doubles, 8 + 16384);
     return IQHIP_OK;
 }
-extern "C" void *iqhip_result_device_ptr(iqhip_engine *e) { return e ? (void *)e->d_result : nullptr; }
+extern "C" void *iqhip_result_device_ptr(iqhip_engine *e) { return (e && e->shards.empty()) ? (void *)e->d_result : nullptr; }
 extern "C" int iqhip_result_capacity(iqhip_engine *e) { return e ? e->result_cap : 0; }
 
 extern "C" int iqhip_result_read(iqhip_engine *e, double *out, int ndoubles) {
+    if (e && !e->shards.empty())
+        return fail(IQHIP_ERR_UNSUPPORTED, "a sharded engine reduces its results itself: use the synchronous calls");
     if (!e || !out || ndoubles < 0 || ndoubles > e->result_cap)
         return fail(IQHIP_ERR_INVALID, "iqhip_result_read: bad arguments");
     HIPCHK(hipSetDevice(e->device));
@@ -1237,6 +1506,7 @@ extern "C" int iqhip_result_read(iqhip_engine *e, double *out, int ndoubles) {
 
 extern "C" int iqhip_synchronize(iqhip_engine *e) {
     if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    if (!e->shards.empty()) return sharded::synchronize(e);
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->staging_busy = false;
@@ -1264,6 +1534,7 @@ static int fetch_vec(iqhip_engine *e, const double *dptr, double *out) {
 
 extern "C" int iqhip_fetch_partial(iqhip_engine *e, uint64_t key, double *out) {
     if (!e || !out) return fail(IQHIP_ERR_INVALID, "null argument");
+    if (!e->shards.empty()) return sharded::fetch_vec(e, key, false, out);
     HIPCHK(hipSetDevice(e->device));
     int idx;
     int rc = slab_for_key(e, key, false, &idx);
@@ -1273,12 +1544,14 @@ extern "C" int iqhip_fetch_partial(iqhip_engine *e, uint64_t key, double *out) {
 
 extern "C" int iqhip_fetch_theta(iqhip_engine *e, double *out) {
     if (!e || !out) return fail(IQHIP_ERR_INVALID, "null argument");
+    if (!e->shards.empty()) return sharded::fetch_vec(e, 0, true, out);
     HIPCHK(hipSetDevice(e->device));
     return fetch_vec(e, e->d_theta, out);
 }
 
 extern "C" int iqhip_fetch_scale_num(iqhip_engine *e, uint64_t key, int16_t *out) {
     if (!e || !out) return fail(IQHIP_ERR_INVALID, "null argument");
+    if (!e->shards.empty()) return sharded::fetch_scale_num(e, key, out);
     HIPCHK(hipSetDevice(e->device));
     int idx;
     int rc = slab_for_key(e, key, false, &idx);
@@ -1290,6 +1563,7 @@ extern "C" int iqhip_fetch_scale_num(iqhip_engine *e, uint64_t key, int16_t *out
 
 extern "C" int iqhip_fetch_pattern_lh(iqhip_engine *e, double *out) {
     if (!e || !out) return fail(IQHIP_ERR_INVALID, "null argument");
+    if (!e->shards.empty()) return sharded::fetch_pattern_lh(e, out, 0, iqhip_branch_end{0, -1, 0}, iqhip_branch_end{0, -1, 0});
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(out, e->d_pattern_lh, sizeof(double) * (size_t)e->nptn, hipMemcpyDeviceToHost));
@@ -1319,6 +1593,7 @@ static int scaled_pattern_lh(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_e
 
 extern "C" int iqhip_fetch_pattern_lh_scaled(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b, double *out) {
     if (!e || !out) return fail(IQHIP_ERR_INVALID, "null argument");
+    if (!e->shards.empty()) return sharded::fetch_pattern_lh(e, out, 1, a, b);
     HIPCHK(hipSetDevice(e->device));
     int rc = scaled_pattern_lh(e, a, b);
     if (rc) return rc;
@@ -1329,6 +1604,7 @@ extern "C" int iqhip_fetch_pattern_lh_scaled(iqhip_engine *e, iqhip_branch_end a
 
 extern "C" int iqhip_pattern_lh_cat(iqhip_engine *e, double len, double *out) {
     if (!e || !out) return fail(IQHIP_ERR_INVALID, "null argument");
+    if (!e->shards.empty()) return sharded::pattern_lh_cat(e, len, out);
     if (!e->theta_valid) return fail(IQHIP_ERR_INVALID, "iqhip_pattern_lh_cat needs iqhip_compute_theta first");
     if (!(len >= 0.0)) return fail(IQHIP_ERR_INVALID, "negative or NaN branch length");
     HIPCHK(hipSetDevice(e->device));
@@ -1346,6 +1622,7 @@ extern "C" int iqhip_pattern_lh_cat(iqhip_engine *e, double len, double *out) {
 extern "C" int iqhip_set_boot_samples(iqhip_engine *e, const float *samples, int nsamples) {
     if (!e || (nsamples > 0 && !samples) || nsamples < 0) return fail(IQHIP_ERR_INVALID, "bad bootstrap samples");
     if (nsamples > 16384) return fail(IQHIP_ERR_INVALID, "at most 16384 bootstrap samples");
+    if (!e->shards.empty()) return sharded::set_boot_samples(e, samples, nsamples);
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->d_boot) HIPCHK(hipFree(e->d_boot));
@@ -1363,6 +1640,8 @@ extern "C" int iqhip_set_boot_samples(iqhip_engine *e, const float *samples, int
 
 extern "C" int iqhip_rell_async(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b) {
     if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    if (!e->shards.empty())
+        return fail(IQHIP_ERR_UNSUPPORTED, "a sharded engine reduces its results itself: use the synchronous calls");
     if (e->nboot == 0) return fail(IQHIP_ERR_INVALID, "no bootstrap samples (iqhip_set_boot_samples)");
     if (e->nboot > e->result_cap) return fail(IQHIP_ERR_INVALID, "result buffer too small for the sample count");
     HIPCHK(hipSetDevice(e->device));
@@ -1374,7 +1653,10 @@ extern "C" int iqhip_rell_async(iqhip_engine *e, iqhip_branch_end a, iqhip_branc
 
 extern "C" int iqhip_rell(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b, double *rell) {
     if (!rell) return fail(IQHIP_ERR_INVALID, "null argument");
+    if (e && !e->shards.empty()) return sharded::rell(e, a, b, rell);
     int rc = iqhip_rell_async(e, a, b);
+    if (rc) return rc;
+    rc = comm_allreduce(e, e->nboot);
     if (rc) return rc;
     rc = read_result(e, e->nboot);
     if (rc) return rc;
@@ -1385,6 +1667,7 @@ extern "C" int iqhip_rell(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end 
 extern "C" int iqhip_upload_partial(iqhip_engine *e, uint64_t key, const double *partial_lh,
                                     const int16_t *scale_num) {
     if (!e || !partial_lh || !scale_num) return fail(IQHIP_ERR_INVALID, "null argument");
+    if (!e->shards.empty()) return sharded::upload_partial(e, key, partial_lh, scale_num);
     HIPCHK(hipSetDevice(e->device));
     int idx;
     int rc = slab_for_key(e, key, true, &idx);
@@ -1406,12 +1689,31 @@ extern "C" int iqhip_upload_partial(iqhip_engine *e, uint64_t key, const double 
 // ---------------------------------------------------------------------------------------
 extern "C" int iqhip_timing_enable(iqhip_engine *e, int on) {
     if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    if (!e->shards.empty()) {
+        for (iqhip_engine *c : e->shards) c->timing = on != 0;
+        return IQHIP_OK;
+    }
     e->timing = on != 0;
     return IQHIP_OK;
 }
 
 extern "C" int iqhip_timing_read(iqhip_engine *e, double *avg_ms, int64_t *launches, int reset) {
     if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    if (!e->shards.empty()) {  // the slowest shard's average; launches of shard 0
+        double worst = 0.0;
+        int64_t n0 = 0;
+        for (size_t g = 0; g < e->shards.size(); g++) {
+            double a = 0.0;
+            int64_t n = 0;
+            int rc = iqhip_timing_read(e->shards[g], &a, &n, reset);
+            if (rc) return rc;
+            if (a > worst) worst = a;
+            if (g == 0) n0 = n;
+        }
+        if (avg_ms) *avg_ms = worst;
+        if (launches) *launches = n0;
+        return IQHIP_OK;
+    }
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     double total = 0.0;

@@ -70,6 +70,68 @@ struct Slab {
     int16_t *sc = nullptr;
 };
 
+// Optimization::minimizeNewton (optimization.cpp:388-465) as a state machine that is advanced once per derivative
+// evaluation: `newton_init`, then after every evaluation at `rts` one `newton_update(sum f*df_ptn, sum f*ddf_ptn)`
+// until `done`.  The same function runs in a 1-thread kernel (sharded engines: derivative kernel -> all-reduce of
+// {df, ddf} -> update kernel, all enqueued, no host round trip per step), on the host (single-process sharding with
+// the pinned-host reduction) and in the CPU tests; k_newton / k_newton_batch keep the loop form.
+struct __attribute__((aligned(16))) NewtonState {
+    double x1, x2, xacc;
+    double rts, rts_old, xl, xh, dx, f, df, d2l, result;
+    int32_t max_steps, j, neval, status;  // status: 0 ok, 2 non-finite derivative, 3 step limit
+    int32_t done, _pad[3];
+};
+
+__host__ __device__ inline void newton_init(NewtonState &s, double xguess, double x1, double x2, double xacc,
+                                            int max_steps) {
+    s.x1 = x1; s.x2 = x2; s.xacc = xacc;
+    s.rts = xguess;
+    if (s.rts < x1) s.rts = x1;
+    if (s.rts > x2) s.rts = x2;
+    s.rts_old = s.rts; s.xl = x1; s.xh = x2; s.dx = 0.0; s.f = s.df = s.d2l = 0.0;
+    s.result = s.rts;
+    s.max_steps = max_steps; s.j = 0; s.neval = 0; s.status = 0; s.done = 0;
+    s._pad[0] = s._pad[1] = s._pad[2] = 0;
+}
+
+__host__ __device__ inline bool newton_finite(double v) { return v == v && v - v == 0.0; }
+
+__host__ __device__ inline void newton_update(NewtonState &s, double pdf, double pddf) {
+    if (s.done) return;
+    if (!newton_finite(pdf)) { pdf = 0.0; pddf = 0.0; }  // computeLikelihoodDerv, phylokernel.h:647-651
+    const double f = -pdf, df = -pddf;                     // computeFuncDerv, phylotree.cpp:2135-2146
+    s.f = f; s.df = df;
+    s.neval++;
+    if (s.neval == 1) {
+        s.d2l = df;
+        if (!newton_finite(f) || !newton_finite(df)) { s.status = 2; s.result = s.rts; s.done = 1; return; }
+        if (df >= 0.0 && fabs(f) < s.xacc) { s.result = s.rts; s.done = 1; return; }
+        if (f < 0.0) { s.xl = s.rts; s.xh = s.x2; } else { s.xh = s.rts; s.xl = s.x1; }
+        s.dx = fabs(s.xh - s.xl);
+        s.j = 1;
+    } else {
+        if (!newton_finite(f) || !newton_finite(df)) { s.status = 2; s.result = s.rts_old; s.done = 1; return; }
+        if (df > 0.0 && fabs(f) < s.xacc) { s.d2l = df; s.result = s.rts; s.done = 1; return; }
+        if (f < 0.0) s.xl = s.rts; else s.xh = s.rts;
+        s.j++;
+        if (s.j > s.max_steps) { s.status = 3; s.result = s.rts; s.done = 1; return; }
+    }
+    s.rts_old = s.rts;
+    if ((df <= 0.0) || (((s.rts - s.xh) * df - f) * ((s.rts - s.xl) * df - f) >= 0.0)) {
+        s.dx = 0.5 * (s.xh - s.xl);
+        s.rts = s.xl + s.dx;
+        s.d2l = df;
+        if (s.xl == s.rts) { s.result = s.rts; s.done = 1; return; }
+    } else {
+        s.dx = f / df;
+        const double temp = s.rts;
+        s.rts -= s.dx;
+        s.d2l = df;
+        if (temp == s.rts) { s.result = s.rts; s.done = 1; return; }
+    }
+    if (fabs(s.dx) < s.xacc || s.j == s.max_steps) { s.result = s.rts_old; s.done = 1; return; }
+}
+
 }  // namespace iqhip
 
 struct iqhip_engine {
@@ -158,6 +220,18 @@ struct iqhip_engine {
     unsigned int batch_launches = 0;
     int num_cus = 256;
     int result_cap = 0;
+    // ---- collectives (comm.hip).  comm != nullptr: this engine is one rank of a pattern-sharded run; every
+    // host-visible sum is all-reduced (ncclAllReduce, SUM, f64, in place in the device result vector, on the engine's
+    // stream) before it is read back.  RCCL is loaded lazily (dlopen) the first time a communicator is made.
+    void *comm = nullptr;            // ncclComm_t
+    int comm_nranks = 1, comm_rank = 0;
+    double *d_result_dev = nullptr;  // device-memory result vector of a comm engine (the default one is mapped host memory)
+    iqhip::NewtonState *d_nstate = nullptr, *h_nstate = nullptr;  // Newton state machine: device copy / pinned host copy
+    // ---- single-process sharding (sharded.hip): this object owns no device memory, it fronts `shards`
+    // (pattern ranges [shard_first[g], shard_first[g+1]) on the devices of iqhip_create_sharded)
+    std::vector<iqhip_engine *> shards;
+    std::vector<int64_t> shard_first;
+    int reduce_mode = 0;             // IQHIP_REDUCE_RCCL / IQHIP_REDUCE_HOST
     // pinned host staging
     iqhip::DevOp *h_ops = nullptr;
     double *h_result = nullptr;
@@ -185,11 +259,62 @@ struct iqhip_engine {
 
 namespace iqhip {
 
+// engine.hip: records the calling thread's error text (iqhip_last_error) and returns `code`
+int set_error(int code, const std::string &msg);
+
+// comm.hip -- RCCL, loaded lazily.  comm_allreduce: in-place SUM/f64 all-reduce of the first n doubles of the
+// engine's device result vector on its stream (no-op without a communicator).  comm_group_allreduce: the same for
+// the shards of a single-process sharded engine, inside one ncclGroupStart/End.  comm_init_all: ncclCommInitAll
+// over the shards' devices.  All return an IQHIP status.
+int comm_allreduce(iqhip_engine *e, int n);
+int comm_group_allreduce(const std::vector<iqhip_engine *> &shards, int n);
+int comm_init_all(const std::vector<iqhip_engine *> &shards);
+void comm_destroy(iqhip_engine *e);
+int comm_use_device_result(iqhip_engine *e);  // switch the engine to a device-memory result vector
+
+// engine.hip internals the sharded front drives its shards with
+int eng_read_result(iqhip_engine *e, int ndoubles);   // D2H of the result vector (if it is device memory) + stream sync
+int eng_repair_lnl(iqhip_engine *e, double *lnl);     // phylokernel.h:848-866 on this engine's _pattern_lh -> its own sum
+int newton_state_alloc(iqhip_engine *e);
+int newton_state_read(iqhip_engine *e);               // -> e->h_nstate (syncs the stream)
+int eng_newton_begin(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps);
+int eng_newton_eval_enqueue(iqhip_engine *e);         // derivative kernel at state->rts + k_reduce -> result[0..1]
+int eng_newton_update_enqueue(iqhip_engine *e);       // state machine step from result[0..1]
+
+// sharded.hip -- the single-process multi-device front (iqhip_create_sharded); every public entry point of
+// engine.hip forwards here when e->shards is non-empty
+namespace sharded {
+void destroy(iqhip_engine *p);
+int reserve(iqhip_engine *p, int nvectors);
+int release(iqhip_engine *p, uint64_t key);
+int rekey(iqhip_engine *p, uint64_t old_key, uint64_t new_key);
+int set_alignment(iqhip_engine *p, const uint8_t *states, const double *ptn_freq, const double *ptn_invar);
+int set_ptn_array(iqhip_engine *p, const double *v, bool invar);
+int set_model(iqhip_engine *p, int nclass, const int32_t *cat_class, const double *eval, const double *evec,
+              const double *inv_evec, const double *rates, const double *props, int state_unknown, const double *tip);
+int traverse(iqhip_engine *p, const iqhip_node_op *ops, int nops, bool has_root, iqhip_branch_end a, iqhip_branch_end b,
+             double len, double *sum_scale, double *lnl);
+int compute_theta(iqhip_engine *p, iqhip_branch_end a, iqhip_branch_end b);
+int derv(iqhip_engine *p, double len, double *df, double *ddf);
+int lnl_from_theta(iqhip_engine *p, double len, double *lnl);
+int optimize_branch(iqhip_engine *p, const iqhip_node_op *ops, int nops, bool build_theta, iqhip_branch_end a,
+                    iqhip_branch_end b, double xguess, double x1, double x2, double xacc, int max_steps,
+                    double *sum_scale, double *optx, double *d2l, int *nsteps);
+int fetch_scale_num(iqhip_engine *p, uint64_t key, int16_t *out);
+int fetch_pattern_lh(iqhip_engine *p, double *out, int kind, iqhip_branch_end a, iqhip_branch_end b);  // kind 0 plain, 1 scaled
+int fetch_vec(iqhip_engine *p, uint64_t key, bool theta, double *out);
+int pattern_lh_cat(iqhip_engine *p, double len, double *out);
+int upload_partial(iqhip_engine *p, uint64_t key, const double *partial_lh, const int16_t *scale_num);
+int set_boot_samples(iqhip_engine *p, const float *samples, int nsamples);
+int rell(iqhip_engine *p, iqhip_branch_end a, iqhip_branch_end b, double *out);
+int synchronize(iqhip_engine *p);
+}  // namespace sharded
+
 // kernels_valu4.hip
 // seg_table: device ints {begin, nops} x nsegs; every segment runs on its own set of workgroups
 hipError_t launch_traverse4(iqhip_engine *e, const int *seg_table, int nsegs, bool has_load, const DevBranch *root, int nwaves);
 hipError_t launch_theta4(iqhip_engine *e, const DevBranch &br);
-hipError_t launch_derv4(iqhip_engine *e, double len, int nwaves);
+hipError_t launch_derv4(iqhip_engine *e, double len, int nwaves, const NewtonState *st = nullptr);
 hipError_t launch_lnl_theta4(iqhip_engine *e, double len, int nwaves);
 hipError_t launch_reduce(iqhip_engine *e, int first_row, int nrows, int nwaves);
 
@@ -199,6 +324,12 @@ hipError_t launch_reduce(iqhip_engine *e, int first_row, int nrows, int nwaves);
 hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps,
                          double *out, const DevBranch *build_from = nullptr, int reduce_rows = 0,
                          int reduce_nwaves = 0);
+
+// Newton as a chain of enqueued steps (kernels_newton.hip): state init, derivative evaluation at state->rts
+// (skipped once state->done), state update from result[0..1]
+hipError_t launch_newton_state_init(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps);
+hipError_t launch_derv_at_state(iqhip_engine *e, int nwaves);
+hipError_t launch_newton_state_update(iqhip_engine *e);
 
 // kernels_rell.hip
 hipError_t launch_pattern_lh_scaled(iqhip_engine *e, const int16_t *sc_a, const int16_t *sc_b, double *out);
@@ -216,6 +347,7 @@ void newton_task_fill(void *dst, const DevBranch &br, double xguess, double x1, 
 hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs, int nwaves);
 int mfma2_fixed_lds_doubles(int n);
 // mode 0: branch lnL, 1: theta, 2: df/ddf from theta, 3: lnL from theta
-hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, double len, int nwaves);
+hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, double len, int nwaves,
+                              const NewtonState *st = nullptr);
 
 }  // namespace iqhip

@@ -971,6 +971,7 @@ struct StreamMArgs {
     int n;
     int ncat;
     double len;
+    const NewtonState *st;    // a step of the enqueued Newton chain: len = st->rts, nothing to do once st->done
 };
 
 template <int MODE>
@@ -978,11 +979,16 @@ __global__ __launch_bounds__(256) void k_stream_mfma(const StreamMArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int N = A.n, B = A.n * A.ncat;
     double *s_v0 = smem, *s_v1 = smem + B, *s_v2 = smem + 2 * B;
+    double len = A.len;
+    if (A.st) {
+        if (A.st->done) return;
+        len = A.st->rts;
+    }
     if (MODE != 1) {
         for (int t = threadIdx.x; t < B; t += 256) {
             const int c = t / N, i = t - c * N;
             const double cof = A.eval[t] * A.rates[c];  // eval: per-category expansion [ncat][n]
-            const double v = exp(cof * A.len) * A.props[c];
+            const double v = exp(cof * len) * A.props[c];
             s_v0[t] = v;
             s_v1[t] = cof * v;
             s_v2[t] = cof * (cof * v);
@@ -1072,8 +1078,10 @@ __global__ __launch_bounds__(256) void k_stream_mfma(const StreamMArgs A) {
     }
 }
 
-hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, double len, int nwaves) {
+hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, double len, int nwaves,
+                              const NewtonState *st) {
     StreamMArgs A;
+    A.st = st;
     if (br) A.br = *br; else A.br = DevBranch{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.0};
     A.tip = e->d_tipc;
     A.eval = e->d_evalc;

@@ -484,6 +484,45 @@ hipError_t launch_newton_batch(iqhip_engine *e, const void *d_tasks, int ntasks,
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// Newton as a chain of enqueued steps (sharded engines: every step needs an all-reduce of {df, ddf} across the
+// ranks, so the loop cannot live inside one kernel).  Per step the engine enqueues
+//     derivative kernel at state->rts -> k_reduce -> ncclAllReduce(result[0..1]) -> k_newton_state_update
+// and reads the state back once per chunk of steps; steps enqueued after `done` are no-ops.
+// ---------------------------------------------------------------------------------------
+__global__ void k_newton_state_init(NewtonState *st, double xguess, double x1, double x2, double xacc, int max_steps) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        NewtonState s;
+        newton_init(s, xguess, x1, x2, xacc, max_steps);
+        *st = s;
+    }
+}
+
+__global__ void k_newton_state_update(NewtonState *st, const double *result) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        NewtonState s = *st;
+        if (!s.done) {
+            newton_update(s, result[0], result[1]);
+            *st = s;
+        }
+    }
+}
+
+hipError_t launch_newton_state_init(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps) {
+    hipLaunchKernelGGL(k_newton_state_init, dim3(1), dim3(64), 0, e->stream, e->d_nstate, xguess, x1, x2, xacc, max_steps);
+    return hipGetLastError();
+}
+
+hipError_t launch_derv_at_state(iqhip_engine *e, int nwaves) {
+    if (e->mfma) return launch_stream_mfma(e, 2, nullptr, 0.0, nwaves, e->d_nstate);
+    return launch_derv4(e, 0.0, nwaves, e->d_nstate);
+}
+
+hipError_t launch_newton_state_update(iqhip_engine *e) {
+    hipLaunchKernelGGL(k_newton_state_update, dim3(1), dim3(64), 0, e->stream, e->d_nstate, e->d_result);
+    return hipGetLastError();
+}
+
 hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps,
                          double *out, const DevBranch *build_from, int reduce_rows, int reduce_nwaves) {
     NewtonArgs A;

@@ -598,9 +598,14 @@ __global__ __launch_bounds__(256) void k_theta_reduce4(
     const double *__restrict__ rates, const double *__restrict__ props, double len,
     const double *__restrict__ freq, const double *__restrict__ invar,
     double *__restrict__ pattern_lh, double *__restrict__ slab, int64_t ntiles, int64_t nptn,
-    int nwaves, int64_t nobs, const int16_t *__restrict__ a_sc, const int16_t *__restrict__ b_sc) {
+    int nwaves, int64_t nobs, const int16_t *__restrict__ a_sc, const int16_t *__restrict__ b_sc,
+    const NewtonState *st) {
     constexpr int B = 4 * C;
     __shared__ double s_v0[B], s_v1[B], s_v2[B];
+    if (st) {  // a step of the enqueued Newton chain: the branch length is the state's current iterate
+        if (st->done) return;
+        len = st->rts;
+    }
     if (threadIdx.x < B) {
         const int c = threadIdx.x >> 2, i = threadIdx.x & 3;
         const double cof = eval[i] * rates[c];
@@ -671,14 +676,14 @@ __global__ __launch_bounds__(256) void k_theta_reduce4(
 }
 
 template <int MODE>
-static hipError_t launch_theta_reduce(iqhip_engine *e, double len, int nwaves) {
+static hipError_t launch_theta_reduce(iqhip_engine *e, double len, int nwaves, const NewtonState *st = nullptr) {
     const int grid = (int)((e->ntiles + 3) / 4);
 #define IQ_TR(Cv)                                                                              \
     case Cv:                                                                                   \
         hipLaunchKernelGGL((k_theta_reduce4<Cv, MODE>), dim3(grid), dim3(256), 0, e->stream,   \
                            e->d_theta, e->d_eval, e->d_rates, e->d_props, len, e->d_freq,      \
                            e->d_invar, e->d_pattern_lh, e->d_slab, e->ntiles, e->nptn, nwaves,  \
-                           e->nptn - e->n_unobs, e->theta_a_sc, e->theta_b_sc);                \
+                           e->nptn - e->n_unobs, e->theta_a_sc, e->theta_b_sc, st);            \
         break;
     switch (e->ncat) {
         IQ_TR(1) IQ_TR(2) IQ_TR(3) IQ_TR(4) IQ_TR(5) IQ_TR(6) IQ_TR(7) IQ_TR(8)
@@ -688,8 +693,8 @@ static hipError_t launch_theta_reduce(iqhip_engine *e, double len, int nwaves) {
     return hipGetLastError();
 }
 
-hipError_t launch_derv4(iqhip_engine *e, double len, int nwaves) {
-    return launch_theta_reduce<0>(e, len, nwaves);
+hipError_t launch_derv4(iqhip_engine *e, double len, int nwaves, const NewtonState *st) {
+    return launch_theta_reduce<0>(e, len, nwaves, st);
 }
 hipError_t launch_lnl_theta4(iqhip_engine *e, double len, int nwaves) {
     return launch_theta_reduce<1>(e, len, nwaves);

@@ -72,6 +72,12 @@ int iqhost_set_mem_mode(void *h, int lm) {
 }
 int iqhost_set_kernel(void *h, int lk) { IQHOST_TRY(((PhyloTree *)h)->setLikelihoodKernel((LikelihoodKernel)lk)); }
 int iqhost_attach_engine(void *h, int device) { IQHOST_TRY(((PhyloTree *)h)->attachEngine(device)); }
+int iqhost_attach_engine_sharded(void *h, const int *device_ids, int ndev, int reduce_mode) {
+    IQHOST_TRY(((PhyloTree *)h)->attachEngineSharded(device_ids, ndev, reduce_mode));
+}
+int iqhost_attach_comm(void *h, int nranks, int rank, const void *unique_id) {
+    IQHOST_TRY(((PhyloTree *)h)->attachComm(nranks, rank, unique_id));
+}
 int iqhost_set_device_newton(void *h, int on) { IQHOST_TRY(((PhyloTree *)h)->device_newton = on != 0); }
 long iqhost_num_derv_calls(void *h) { return ((PhyloTree *)h)->num_derv_calls; }
 int iqhost_set_heavy_first(void *h, int on) { IQHOST_TRY(((PhyloTree *)h)->heavy_first = on != 0); }

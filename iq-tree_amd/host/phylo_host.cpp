@@ -363,6 +363,22 @@ void PhyloTree::attachEngine(int device) {
     check(iqhip_reserve(engine, nvec), "iqhip_reserve");
 }
 
+void PhyloTree::attachEngineSharded(const int *device_ids, int ndev, int reduce_mode) {
+    if (engine) throw std::runtime_error("engine already attached");
+    if (m_eval.empty() || aln_states.empty()) throw std::runtime_error("setAlignment and setModel first");
+    check(iqhip_create_sharded(&engine, device_ids, ndev, reduce_mode, num_states, ncat, nptn, leafNum),
+          "iqhip_create_sharded");
+    inputs_dirty = model_dirty = aln_dirty = true;
+    pushInputs();
+    int nvec = (lh_mem_save == LM_PER_NODE) ? (leafNum - 2) : (3 * leafNum - 6);
+    check(iqhip_reserve(engine, nvec), "iqhip_reserve");
+}
+
+void PhyloTree::attachComm(int nranks, int rank, const void *unique_id) {
+    if (!engine) throw std::runtime_error("attachEngine first");
+    check(iqhip_comm_init_rank(engine, nranks, rank, unique_id), "iqhip_comm_init_rank");
+}
+
 void PhyloTree::pushInputs() {
     if (!engine || !inputs_dirty) return;
     // a model change re-sends the model only: the alignment (megabytes of state rows) stays where it is

@@ -122,6 +122,11 @@ public:
     LhMemSave lh_mem_save = LM_PER_NODE;
     // device: >= 0 creates an engine on that GPU; dry_run records plans without any device
     void attachEngine(int device);
+    // pattern-sharded engines (include/iqhip.h "pattern sharding over GPUs"): one handle over several GPUs of this
+    // process, or this process's engine joined to the other ranks' (one process per GPU); nothing else changes for
+    // the callers below -- every host-visible sum is all-reduced inside the engine
+    void attachEngineSharded(const int *device_ids, int ndev, int reduce_mode);
+    void attachComm(int nranks, int rank, const void *unique_id);
     void setDryRun(bool on) { dry_run = on; }
     bool heavy_first = true;  // plan order of independent subtrees (see collectPlan)
     // optimizeOneBranch: run the whole Newton-Raphson solve on the device (iqhip_newton_branch)

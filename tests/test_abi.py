@@ -22,7 +22,7 @@ def test_every_declared_symbol_is_exported(pkg):
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(pkg.IQHIP_SYMBOLS) == names
-    assert lib.iqhip_abi_version() == 1
+    assert lib.iqhip_abi_version() == 2
 
 
 def test_struct_layout_matches_header(pkg):

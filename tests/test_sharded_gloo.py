@@ -83,7 +83,21 @@ def _worker(rank, world, port, q):
     lnl = t.compute_likelihood()
     a, b = t.current_branch()
     sf = t.neighbor_info(a, b)["lh_scale_factor"]
-    q.put((rank, lnl, sf))
+    # ---- hot loop 2 under sharding: df/ddf of a branch are all-reduced per evaluation and every rank advances the
+    # engine's Newton state machine (the function the sharded engines run in a 1-thread kernel after the in-stream
+    # all-reduce); all ranks take identical steps and end on the full-alignment optimum
+    inner = [(x, y) for x in shard.adj for y, _ in shard.adj[x] if x < y and not shard.is_leaf(x) and not shard.is_leaf(y)]
+    x, y = inner[len(inner) // 2]
+    th, _ = shard.theta(x, y)
+    m = pkg.NewtonStateMachine(shard.length(x, y), 1e-6, 100.0, 1e-6, 100)
+    xs = []
+    while not m.done:
+        xs.append(m.x)
+        d = torch.tensor(shard.derv(x, y, length=m.x, theta=th), dtype=torch.float64)
+        dist.all_reduce(d, op=dist.ReduceOp.SUM)
+        m.update(float(d[0]), float(d[1]))
+    optx, d2l, nsteps, status = m.result()
+    q.put((rank, lnl, sf, (x, y), xs, optx, status))
     dist.destroy_process_group()
 
 
@@ -107,7 +121,21 @@ def test_two_rank_pattern_sharding_reduces_to_full_lnl(oracle, synth):
     ref, (a, b) = full.likelihood()
     sf_ref = full.partial(a, b)[2]
     assert sf_ref < 0  # scaling happened, so sum_scale entries took part in the reduction
-    for rank, lnl, sf in res:
+    for rank, lnl, sf, *_ in res:
         assert abs(lnl - ref) <= 1e-11 * abs(ref), (rank, lnl, ref)
         assert abs(sf - sf_ref) <= 1e-11 * abs(sf_ref)
     assert res[0][1] == res[1][1]  # every rank holds the identical reduced value
+    # Newton under sharding: both ranks evaluated the same points and agree with the one-rank solve on all patterns
+    (x, y), xs0, optx0, st0 = res[0][3], res[0][4], res[0][5], res[0][6]
+    assert res[1][3] == (x, y) and res[1][4] == xs0 and res[1][5] == optx0 and st0 == 0 and res[1][6] == 0
+    from conftest import load_package
+    pkg = load_package()
+    th, _ = full.theta(x, y)
+    m = pkg.NewtonStateMachine(full.length(x, y), 1e-6, 100.0, 1e-6, 100)
+    xs = []
+    while not m.done:
+        xs.append(m.x)
+        m.update(*full.derv(x, y, length=m.x, theta=th))
+    assert len(xs) == len(xs0) and len(xs0) >= 2
+    np.testing.assert_allclose(xs0, xs, rtol=1e-9)
+    assert abs(m.result()[0] - optx0) <= 1e-9 * optx0
