@@ -72,7 +72,13 @@ typedef struct iqhip_node_op {
     int32_t right_leaf;
     double left_len;  /* PhyloNeighbor::length of the left child branch  */
     double right_len; /* ... of the right child branch */
+    uint32_t flags;   /* IQHIP_OP_* */
+    uint32_t _pad;
 } iqhip_node_op;
+/* IQHIP_OP_NO_SCALE: never rescale this result.  A node of degree > 3 (the reference's scalar kernel multiplies ALL
+ * children, applies U^-1 and tests for underflow once, phylotreesse.cpp:702-806) is submitted as a chain of binary
+ * updates whose intermediate products travel over zero-length branches and carry this flag (iqhip_adapter.h). */
+enum { IQHIP_OP_NO_SCALE = 1 };
 
 /* One end of a branch for the lnL / theta calls. leaf >= 0 -> taxon id, else key. */
 typedef struct iqhip_branch_end {

@@ -2,8 +2,10 @@
 //
 // This file is what an IQ-TREE maintainer adds to the reference tree (next to phylotreesse.cpp);
 // it is NOT built in this repository (it includes the reference's own headers, and the reference
-// cannot be built in this image -- see DESIGN.md).  The same logic, on a stand-alone copy of the
-// PhyloTree slice, is what iq-tree_amd/host/phylo_host.cpp implements and what the tests run.
+// cannot be built in this image -- see DESIGN.md).  It holds only what is specific to the reference's
+// classes: kernel selection, engine set-up from Alignment / ModelFactory / RateHeterogeneity (hipSync),
+// a policy struct naming the reference's types, member wrappers and lazy host views.  ALL adapter logic
+// is include/iqhip_adapter.h, which this repository compiles and tests through its own instantiation.
 //
 // Wiring (see INTEGRATION.md for the three small hunks in existing files):
 //   phylotree.h      + four member declarations, + `struct iqhip_engine *hip_engine;`
@@ -29,6 +31,16 @@
     } while (0)
 
 static inline uint64_t hipKey(PhyloNeighbor *nei) { return (uint64_t)(uintptr_t)nei->get_partial_lh(); }
+
+// multi-GPU: `-hip-devices 0,1,..,7` (params->hip_devices) makes ONE engine over several GPUs of this process
+// (iqhip_create_sharded: patterns sharded, one RCCL all-reduce per evaluation inside the engine); nothing else in
+// this file changes
+static int hipCreateEngine(iqhip_engine **e, Params *params, int nstates, int ncat, size_t nptn, int ntaxa) {
+    if (params->hip_devices.size() > 1)
+        return iqhip_create_sharded(e, &params->hip_devices[0], (int)params->hip_devices.size(), IQHIP_REDUCE_RCCL,
+                                    nstates, ncat, (int64_t)nptn, ntaxa);
+    return iqhip_create(e, params->hip_device, nstates, ncat, (int64_t)nptn, ntaxa);
+}
 
 bool PhyloTree::hipKernelUsable() {
     if (!aln || !model_factory || !model || !site_rate) return false;
@@ -63,7 +75,7 @@ void PhyloTree::hipSync() {
     int ncat = (mix && !fused) ? nrate * nmix : nrate;
     if (!hip_engine || hip_nptn != nptn || hip_ncat != ncat) {
         if (hip_engine) iqhip_destroy(hip_engine);
-        IQHIP_CHECK(iqhip_create(&hip_engine, params->hip_device, aln->num_states, ncat, nptn, leafNum));
+        IQHIP_CHECK(hipCreateEngine(&hip_engine, params, aln->num_states, ncat, nptn, leafNum));
         hip_nptn = nptn;
         hip_ncat = ncat;
         hip_aln_pushed = false;
@@ -107,140 +119,77 @@ void PhyloTree::hipSync() {
     }
 }
 
-struct HipPlanOp { PhyloNeighbor *dst, *left, *right; };
+// ---------------------------------------------------------------------------------------------------------------
+// Everything below the engine set-up is include/iqhip_adapter.h -- recursion, lazy flags, LM_PER_NODE re-orientation,
+// lh_scale_factor bookkeeping, leaf-side swap, the bodies of the four kernels, multifurcating nodes -- instantiated
+// with the reference's own types.  The very same templates, instantiated with a stand-alone mirror of these types
+// (iq-tree_amd/host/phylo_host.cpp, MirrorPolicy), are what this repository's test-suite runs on the GPU.
+// phylonode.h / phylotree.h each gain one line: `friend struct HipPolicy;` (PhyloNeighbor's fields are private).
+// ---------------------------------------------------------------------------------------------------------------
+#include "iqhip_adapter.h"
 
-// phylokernel.h:70-157 with the three pattern loops replaced by "append one op"
-void PhyloTree::hipCollectPlan(PhyloNeighbor *dad_branch, PhyloNode *dad, vector<iqhip_node_op> &ops,
-                               vector<HipPlanOp> &plan) {
-    if (dad_branch->partial_lh_computed & 1) return;
-    dad_branch->partial_lh_computed |= 1;
-    num_partial_lh_computations++;
-    PhyloNode *node = (PhyloNode *)dad_branch->node;
-    if (node->isLeaf()) { dad_branch->lh_scale_factor = 0.0; return; }
-    if (node->degree() != 3) outError("HIP likelihood kernel: multifurcating node");  // scalar-only in the reference too
-    PhyloNeighbor *left = NULL, *right = NULL;
-    FOR_NEIGHBOR_IT(node, dad, it) { if (!left) left = (PhyloNeighbor *)(*it); else right = (PhyloNeighbor *)(*it); }
-    if (!left->node->isLeaf() && right->node->isLeaf()) { PhyloNeighbor *t = left; left = right; right = t; }
-    if ((left->partial_lh_computed & 1) == 0) hipCollectPlan(left, node, ops, plan);
-    if ((right->partial_lh_computed & 1) == 0) hipCollectPlan(right, node, ops, plan);
-    if (params->lh_mem_save == LM_PER_NODE && !dad_branch->partial_lh) dad_branch->reorientPartialLh(dad);
-    iqhip_node_op op;
-    memset(&op, 0, sizeof(op));
-    op.dst_key = hipKey(dad_branch);
-    op.left_leaf = left->node->isLeaf() ? left->node->id : -1;
-    op.right_leaf = right->node->isLeaf() ? right->node->id : -1;
-    op.left_key = left->node->isLeaf() ? 0 : hipKey(left);
-    op.right_key = right->node->isLeaf() ? 0 : hipKey(right);
-    op.left_len = left->length;
-    op.right_len = right->length;
-    ops.push_back(op);
-    HipPlanOp p = {dad_branch, left, right};
-    plan.push_back(p);
-}
-
-static void hipApplyScale(vector<HipPlanOp> &plan, vector<double> &sum_scale) {
-    for (size_t k = 0; k < plan.size(); k++)  // phylokernel.h:157,395,477
-        plan[k].dst->lh_scale_factor = plan[k].left->lh_scale_factor + plan[k].right->lh_scale_factor + sum_scale[k];
-}
-
-static iqhip_branch_end hipEnd(PhyloNeighbor *nei) {
-    iqhip_branch_end e;
-    e._pad = 0;
-    e.leaf = nei->node->isLeaf() ? nei->node->id : -1;
-    e.key = nei->node->isLeaf() ? 0 : hipKey(nei);
-    return e;
-}
+struct HipPolicy : iqhip_adapter::EngineCalls<HipPolicy, PhyloTree> {
+    typedef PhyloTree Tree;
+    typedef PhyloNode Node;
+    typedef PhyloNeighbor Neighbor;
+    static Node *node(Neighbor *nb) { return (PhyloNode *)nb->node; }
+    static double length(Neighbor *nb) { return nb->length; }
+    static bool isLeaf(Node *n) { return n->isLeaf(); }
+    static int degree(Node *n) { return n->degree(); }
+    static int leafId(Node *n) { return n->id; }
+    static int numNeighbors(Node *n) { return (int)n->neighbors.size(); }
+    static Neighbor *neighborAt(Node *n, int k) { return (PhyloNeighbor *)n->neighbors[k]; }
+    static Neighbor *findNeighbor(Node *at, Node *to) { return (PhyloNeighbor *)at->findNeighbor(to); }
+    static int &computed(Neighbor *nb) { return nb->partial_lh_computed; }
+    static double &scaleFactor(Neighbor *nb) { return nb->lh_scale_factor; }
+    static uint64_t key(Neighbor *nb) { return (uint64_t)(uintptr_t)nb->partial_lh; }
+    static void stealBuffer(Neighbor *to, Neighbor *from) {  // phylokernel.h:131-137
+        to->partial_lh = from->partial_lh;
+        to->scale_num = from->scale_num;
+        from->partial_lh = NULL;
+        from->scale_num = NULL;
+    }
+    static bool perNodeMode(Tree *t) { return t->params->lh_mem_save == LM_PER_NODE; }
+    static bool heavyFirst(Tree *) { return true; }
+    static void ensureBuffers(Tree *t) { if (!t->central_partial_lh) t->initializeAllPartialLh(); }
+    static void sync(Tree *t) { t->hipSync(); }
+    static iqhip_engine *engine(Tree *t) { return t->hip_engine; }
+    static void fail(Tree *, const char *what, const char *detail) { outError(what, detail); }  // tools.h:1786, exits
+    static void countComputation(Tree *t) { t->num_partial_lh_computations++; }
+    static bool &thetaComputed(Tree *t) { return t->theta_computed; }
+    static Neighbor *currentIt(Tree *t) { return t->current_it; }
+    static Neighbor *currentItBack(Tree *t) { return t->current_it_back; }
+    static double minBranchLength(Tree *t) { return t->params->min_branch_length; }
+    static double maxBranchLength(Tree *t) { return t->params->max_branch_length; }
+};
 
 void PhyloTree::computePartialLikelihoodHIP(PhyloNeighbor *dad_branch, PhyloNode *dad) {
-    if (!central_partial_lh) initializeAllPartialLh();
-    hipSync();
-    vector<iqhip_node_op> ops;
-    vector<HipPlanOp> plan;
-    hipCollectPlan(dad_branch, dad, ops, plan);
-    if (ops.empty()) return;
-    vector<double> sum_scale(ops.size());
-    IQHIP_CHECK(iqhip_update_partials(hip_engine, &ops[0], (int)ops.size(), &sum_scale[0]));
-    hipApplyScale(plan, sum_scale);
+    iqhip_adapter::computePartialLikelihood<HipPolicy>(this, dad_branch, dad);
 }
 
 double PhyloTree::computeLikelihoodBranchHIP(PhyloNeighbor *dad_branch, PhyloNode *dad) {
-    PhyloNode *node = (PhyloNode *)dad_branch->node;
-    PhyloNeighbor *node_branch = (PhyloNeighbor *)node->findNeighbor(dad);
-    if (!central_partial_lh) initializeAllPartialLh();
-    if (node->isLeaf()) {  // phylokernel.h:739-746
-        PhyloNode *tn = dad; dad = node; node = tn;
-        PhyloNeighbor *tb = dad_branch; dad_branch = node_branch; node_branch = tb;
-    }
-    hipSync();
-    vector<iqhip_node_op> ops;
-    vector<HipPlanOp> plan;
-    if ((dad_branch->partial_lh_computed & 1) == 0) hipCollectPlan(dad_branch, dad, ops, plan);
-    if ((node_branch->partial_lh_computed & 1) == 0) hipCollectPlan(node_branch, node, ops, plan);
-    vector<double> sum_scale(ops.size() + 1);
-    double lnl;
-    IQHIP_CHECK(iqhip_traverse_lnl(hip_engine, ops.empty() ? NULL : &ops[0], (int)ops.size(),
-                                   hipEnd(node_branch), hipEnd(dad_branch), dad_branch->length,
-                                   &sum_scale[0], &lnl));
-    hipApplyScale(plan, sum_scale);
     hip_pattern_lh_stale = true;  // _pattern_lh lives on the device until somebody asks (hipFetchPatternLh)
-    return node_branch->lh_scale_factor + dad_branch->lh_scale_factor + lnl;  // phylokernel.h:751
+    return iqhip_adapter::computeLikelihoodBranch<HipPolicy>(this, dad_branch, dad);
 }
 
 void PhyloTree::computeLikelihoodDervHIP(PhyloNeighbor *dad_branch, PhyloNode *dad, double &df, double &ddf) {
-    PhyloNode *node = (PhyloNode *)dad_branch->node;
-    PhyloNeighbor *node_branch = (PhyloNeighbor *)node->findNeighbor(dad);
-    if (!central_partial_lh) initializeAllPartialLh();
-    if (node->isLeaf()) {  // phylokernel.h:491-498
-        PhyloNode *tn = dad; dad = node; node = tn;
-        PhyloNeighbor *tb = dad_branch; dad_branch = node_branch; node_branch = tb;
-    }
-    if ((dad_branch->partial_lh_computed & 1) == 0) computePartialLikelihoodHIP(dad_branch, dad);
-    if ((node_branch->partial_lh_computed & 1) == 0) computePartialLikelihoodHIP(node_branch, node);
-    hipSync();
-    if (!theta_computed) {  // phylokernel.h:535-579
-        theta_computed = true;
-        IQHIP_CHECK(iqhip_compute_theta(hip_engine, hipEnd(node_branch), hipEnd(dad_branch)));
-    }
-    IQHIP_CHECK(iqhip_derv(hip_engine, dad_branch->length, &df, &ddf));
+    iqhip_adapter::computeLikelihoodDerv<HipPolicy>(this, dad_branch, dad, df, ddf);
 }
 
 double PhyloTree::computeLikelihoodFromBufferHIP() {
-    assert(theta_all && theta_computed);
-    double lnl;
-    IQHIP_CHECK(iqhip_lnl_from_theta(hip_engine, current_it->length, &lnl));
     hip_pattern_lh_stale = true;
-    return current_it->lh_scale_factor + current_it_back->lh_scale_factor + lnl;  // phylokernel.h:1028
+    return iqhip_adapter::computeLikelihoodFromBuffer<HipPolicy>(this);
 }
 
 // Optional fast path for hot loop 2: PhyloTree::optimizeOneBranch (phylotree.cpp:2148-2192) with its
 // Newton-Raphson branch `optx = minimizeNewton(...)` replaced by ONE engine submission (pending
-// updates of both ends + theta + the whole minimizeNewton loop on the device).  Hunk in
-// optimizeOneBranch: `if (optimize_by_newton && hip_engine && computePartialLikelihoodPointer ==
-// &PhyloTree::computePartialLikelihoodHIP && model_factory->unobserved_ptns.empty())
-//     optx = hipMinimizeNewton(current_len, maxNRStep); else ...`   (+ASC keeps the host loop)
+// updates of both ends + theta + the whole minimizeNewton loop on the device; on a sharded engine the loop is an
+// enqueued chain with one in-stream all-reduce per step).  Hunk in optimizeOneBranch:
+//   if (optimize_by_newton && hip_engine && computePartialLikelihoodPointer == &PhyloTree::computePartialLikelihoodHIP
+//       && model_factory->unobserved_ptns.empty())
+//       optx = hipMinimizeNewton(current_len, maxNRStep); else ...        (+ASC keeps the host loop)
 double PhyloTree::hipMinimizeNewton(double current_len, int maxNRStep) {
-    PhyloNeighbor *dad_branch = current_it, *node_branch = current_it_back;
-    PhyloNode *dad = (PhyloNode *)current_it_back->node, *node = (PhyloNode *)current_it->node;
-    if (node->isLeaf()) {
-        PhyloNode *tn = dad; dad = node; node = tn;
-        PhyloNeighbor *tb = dad_branch; dad_branch = node_branch; node_branch = tb;
-    }
-    if (!central_partial_lh) initializeAllPartialLh();
-    hipSync();
-    vector<iqhip_node_op> ops;
-    vector<HipPlanOp> plan;
-    if ((dad_branch->partial_lh_computed & 1) == 0) hipCollectPlan(dad_branch, dad, ops, plan);
-    if ((node_branch->partial_lh_computed & 1) == 0) hipCollectPlan(node_branch, node, ops, plan);
-    vector<double> sum_scale(ops.size() + 1);
-    double optx, d2l;
-    int nsteps;
-    theta_computed = true;
-    IQHIP_CHECK(iqhip_optimize_branch(hip_engine, ops.empty() ? NULL : &ops[0], (int)ops.size(), hipEnd(node_branch),
-                                      hipEnd(dad_branch), current_len, params->min_branch_length,
-                                      params->max_branch_length, params->min_branch_length, maxNRStep,
-                                      &sum_scale[0], &optx, &d2l, &nsteps));
-    hipApplyScale(plan, sum_scale);
-    return optx;
+    return iqhip_adapter::minimizeNewtonOnBranch<HipPolicy>(this, current_len, maxNRStep);
 }
 
 // Lazy host views for the few callers that read kernel outputs on the host

@@ -41,7 +41,7 @@ class NodeOp(C.Structure):
     """struct iqhip_node_op (include/iqhip.h)."""
     _fields_ = [("dst_key", C.c_uint64), ("left_key", C.c_uint64), ("right_key", C.c_uint64),
                 ("left_leaf", C.c_int32), ("right_leaf", C.c_int32),
-                ("left_len", C.c_double), ("right_len", C.c_double)]
+                ("left_len", C.c_double), ("right_len", C.c_double), ("flags", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 class BranchEnd(C.Structure):
@@ -591,7 +591,7 @@ class PhyloTree:
         plan = []
         for k in range(n):
             plan.append(dict(dst=(ints[7 * k], ints[7 * k + 1]), left=ints[7 * k + 2], right=ints[7 * k + 3],
-                             left_leaf=ints[7 * k + 4], right_leaf=ints[7 * k + 5],
+                             left_leaf=ints[7 * k + 4], right_leaf=ints[7 * k + 5], flags=ints[7 * k + 6],
                              left_len=lens[2 * k], right_len=lens[2 * k + 1],
                              dst_key=keys[3 * k], left_key=keys[3 * k + 1], right_key=keys[3 * k + 2]))
         return plan

@@ -696,6 +696,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         DevOp &d = e->h_ops[k];
         dummy_op(d);
         d.out_row = order[k];
+        d.no_scale = (o.flags & IQHIP_OP_NO_SCALE) ? 1 : 0;
         if (k > 0 && seg_of[k] != seg_of[k - 1]) prev_dst = -1;  // another workgroup: no register hand-over
         if (!(o.left_len >= 0.0) || !(o.right_len >= 0.0))
             return fail(IQHIP_ERR_INVALID, "negative or NaN branch length");

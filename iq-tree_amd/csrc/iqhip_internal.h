@@ -51,6 +51,7 @@ struct __attribute__((aligned(16))) DevOp {
     int32_t sr_slot;    //   the chunk (slot 0 is shared by all non-leaf children)
     int32_t push_hold;  // 1: copy this op's result into the HOLD registers (consumed by a CHILD_HOLD)
     int32_t out_row;    // row of the caller's op list this op answers (sum_scale[out_row]); plans may be reordered
+    int32_t no_scale;   // IQHIP_OP_NO_SCALE: intermediate product of a multifurcating node, never rescaled
 };
 
 // Root branch descriptor for the lnL / theta kernels.

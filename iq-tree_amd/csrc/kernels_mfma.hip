@@ -206,7 +206,7 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
             // column (pattern) max over the 4 lane groups
             lmax = fmax(lmax, __shfl_xor(lmax, 16, 64));
             lmax = fmax(lmax, __shfl_xor(lmax, 32, 64));
-            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0);
+            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0) && !op.no_scale;
             double my_scale = 0.0;
             if (__any(do_scale)) {
                 if (do_scale) {
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
 #pragma unroll
                 for (int q = 0; q < CS; q++) lmax = fmax(lmax, s_lmax[par][w0 + q][p]);
             }
-            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0);
+            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0) && !op.no_scale;
             double my_scale = 0.0;
             if (__any(do_scale)) {
                 if (do_scale) {
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_mix20(const TravMArgs A
 #pragma unroll
                 for (int q = 0; q < CS; q++) lmax = fmax(lmax, s_lmax[par][w0 + q][p]);
             }
-            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0);
+            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0) && !op.no_scale;
             double my_scale = 0.0;
             if (__any(do_scale)) {
                 if (do_scale) {
@@ -840,7 +840,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_rows64(const TravMArgs 
             if (g == 0) s_lmax[par][wave][p] = lmax;
             __syncthreads();
             lmax = fmax(fmax(s_lmax[par][0][p], s_lmax[par][1][p]), fmax(s_lmax[par][2][p], s_lmax[par][3][p]));
-            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0);
+            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0) && !op.no_scale;
             double my_scale = 0.0;
             if (__any(do_scale)) {
                 if (do_scale) {

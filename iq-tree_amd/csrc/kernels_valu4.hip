@@ -386,7 +386,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
                                                 s_tip, U, uinv, sL, sR, A.state_unknown, nx_pf, dstp, coff, PF, HOLD, prev);
             if (SP == 2) lh_max = fmax(lh_max, __shfl_xor(lh_max, 32, 64));  // both category halves of the pattern
             // ---- scaling (SIMD rule, phylokernel.h:379-392,461-474); TIP-TIP never scales
-            const bool do_scale = !(leafL && leafR) && (lh_max < kScalingThreshold) && (invar == 0.0);
+            const bool do_scale = !(leafL && leafR) && (lh_max < kScalingThreshold) && (invar == 0.0) && !op->no_scale;
             double my_scale = 0.0;
             const unsigned long long any = __ballot(do_scale);
             if (__builtin_expect(any != 0, 0)) {  // rare, wave-uniform

@@ -284,12 +284,12 @@ int iqhost_last_plan(void *h, int *ints, double *lens, uint64_t *keys, int cap) 
             for (PhyloNeighbor *nb : nd->neighbors)
                 if (nb == p.dst) from = nd->id;
         ints[k * 7 + 0] = from;
-        ints[k * 7 + 1] = p.dst->node->id;
-        ints[k * 7 + 2] = p.left->node->id;
-        ints[k * 7 + 3] = p.right->node->id;
+        ints[k * 7 + 1] = p.dst ? p.dst->node->id : -1;
+        ints[k * 7 + 2] = p.left ? p.left->node->id : -1;
+        ints[k * 7 + 3] = p.right ? p.right->node->id : -1;
         ints[k * 7 + 4] = p.op.left_leaf;
         ints[k * 7 + 5] = p.op.right_leaf;
-        ints[k * 7 + 6] = 0;
+        ints[k * 7 + 6] = (int)p.op.flags;
         if (lens) { lens[k * 2] = p.op.left_len; lens[k * 2 + 1] = p.op.right_len; }
         if (keys) { keys[k * 3] = p.op.dst_key; keys[k * 3 + 1] = p.op.left_key; keys[k * 3 + 2] = p.op.right_key; }
     }

@@ -482,207 +482,157 @@ void PhyloTree::clearAllPartialLH() {
 }
 
 // =========================================================================================
-// plan building = phylokernel.h:70-157 without the pattern loops
+// The adapter (include/iqhip_adapter.h) instantiated for this mirror.  The policy answers the adapter's questions
+// about the tree types and wraps the engine calls with what only the mirror has: dry-run mode (CPU tests record
+// plans without a device), the legacy caller-owned collective (allreduce_hook) and the call counters.
 // =========================================================================================
-void PhyloTree::collectPlan(PhyloNeighbor *dad_branch, PhyloNode *dad, std::vector<PlanOp> &plan) {
-    assert(dad);
-    if (dad_branch->partial_lh_computed & 1) return;  // don't recompute (:81-82)
-    dad_branch->partial_lh_computed |= 1;
-    num_partial_lh_computations++;
-    PhyloNode *node = dad_branch->node;
-    if (node->isLeaf()) {
-        dad_branch->lh_scale_factor = 0.0;  // :93-97
-        return;
+}  // namespace iqhost
+
+#include "../../include/iqhip_adapter.h"
+
+namespace iqhost {
+
+struct MirrorPolicy : iqhip_adapter::EngineCalls<MirrorPolicy, PhyloTree> {
+    typedef iqhip_adapter::EngineCalls<MirrorPolicy, PhyloTree> Base;
+    typedef iqhip_adapter::Plan<MirrorPolicy> Plan;
+    typedef PhyloTree Tree;
+    typedef PhyloNode Node;
+    typedef PhyloNeighbor Neighbor;
+    static Node *node(Neighbor *nb) { return nb->node; }
+    static double length(Neighbor *nb) { return nb->length; }
+    static bool isLeaf(Node *n) { return n->isLeaf(); }
+    static int degree(Node *n) { return n->degree(); }
+    static int leafId(Node *n) { return n->id; }
+    static int numNeighbors(Node *n) { return (int)n->neighbors.size(); }
+    static Neighbor *neighborAt(Node *n, int k) { return n->neighbors[k]; }
+    static Neighbor *findNeighbor(Node *at, Node *to) { return at->findNeighbor(to); }
+    static int &computed(Neighbor *nb) { return nb->partial_lh_computed; }
+    static double &scaleFactor(Neighbor *nb) { return nb->lh_scale_factor; }
+    static uint64_t key(Neighbor *nb) { return nb->partial_lh; }
+    static void stealBuffer(Neighbor *to, Neighbor *from) { to->partial_lh = from->partial_lh; from->partial_lh = 0; }
+    static bool perNodeMode(Tree *t) { return t->lh_mem_save == LM_PER_NODE; }
+    static bool heavyFirst(Tree *t) { return t->heavy_first; }
+    static void ensureBuffers(Tree *t) { if (!t->central_partial_lh) t->initializeAllPartialLh(); }
+    static void sync(Tree *t) { t->pushInputs(); }
+    static iqhip_engine *engine(Tree *t) { return t->engine; }
+    static void fail(Tree *, const char *what, const char *detail) {
+        throw std::runtime_error(std::string(what) + ": " + detail);
     }
-    if (node->degree() != 3)
-        throw std::runtime_error("multifurcating node: the reference falls back to its scalar kernel "
-                                 "(phylokernel.h:73-77), which this build does not ship");
-    PhyloNeighbor *left = nullptr, *right = nullptr;
-    for (PhyloNeighbor *nb : node->neighbors)
-        if (nb->node != dad) {
-            if (!left) left = nb; else right = nb;
+    static void countComputation(Tree *t) { t->num_partial_lh_computations++; }
+    static bool &thetaComputed(Tree *t) { return t->theta_computed; }
+    static Neighbor *currentIt(Tree *t) { return t->current_it; }
+    static Neighbor *currentItBack(Tree *t) { return t->current_it_back; }
+    static double minBranchLength(Tree *t) { return t->min_branch_length; }
+    static double maxBranchLength(Tree *t) { return t->max_branch_length; }
+
+    static void record(Tree *t, const Plan &plan) {
+        t->last_plan.clear();
+        for (size_t k = 0; k < plan.ops.size(); k++) {
+            PlanOp p;
+            p.dst = plan.dst[k];
+            const bool binary = plan.dst[k] && plan.kids[k].size() == 2;
+            p.left = binary ? plan.kids[k][0] : nullptr;
+            p.right = binary ? plan.kids[k][1] : nullptr;
+            p.op = plan.ops[k];
+            t->last_plan.push_back(p);
         }
-    if (!left->node->isLeaf() && right->node->isLeaf()) std::swap(left, right);  // :116-121
-    // Visit the subtree with more pending updates first: its result then waits only for the
-    // (short) other subtree before it is consumed, i.e. it is re-read while still cache-resident.
-    // The order of independent subtrees changes no number (each update is a pure function of its
-    // children); the reference simply takes neighbour order (phylokernel.h:122-125).
-    PhyloNeighbor *first = left, *second = right;
-    if (heavy_first && countPending(right, node) > countPending(left, node)) std::swap(first, second);
-    if ((first->partial_lh_computed & 1) == 0) collectPlan(first, node, plan);
-    if ((second->partial_lh_computed & 1) == 0) collectPlan(second, node, plan);
-
-    if (lh_mem_save == LM_PER_NODE && !dad_branch->partial_lh) {
-        // re-orient partial_lh (:127-143): steal the vector of a child-side back neighbour
-        bool done = false;
-        for (PhyloNeighbor *nb : node->neighbors)
-            if (nb->node != dad) {
-                PhyloNeighbor *backnei = nb->node->findNeighbor(node);
-                if (backnei->partial_lh) {
-                    dad_branch->partial_lh = backnei->partial_lh;
-                    backnei->partial_lh = 0;
-                    backnei->partial_lh_computed &= ~1;
-                    done = true;
-                    break;
-                }
-            }
-        if (!done) throw std::runtime_error("partial_lh is not re-oriented");
     }
-    if (!dad_branch->partial_lh) throw std::runtime_error("neighbor has no partial_lh buffer");
-
-    PlanOp p;
-    p.dst = dad_branch;
-    p.left = left;
-    p.right = right;
-    memset(&p.op, 0, sizeof(p.op));
-    p.op.dst_key = dad_branch->partial_lh;
-    p.op.left_leaf = left->node->isLeaf() ? left->node->id : -1;
-    p.op.right_leaf = right->node->isLeaf() ? right->node->id : -1;
-    p.op.left_key = left->node->isLeaf() ? 0 : left->partial_lh;
-    p.op.right_key = right->node->isLeaf() ? 0 : right->partial_lh;
-    p.op.left_len = left->length;
-    p.op.right_len = right->length;
-    plan.push_back(p);
-}
-
-int PhyloTree::countPending(PhyloNeighbor *nei, PhyloNode *dad) const {
-    if ((nei->partial_lh_computed & 1) || nei->node->isLeaf()) return 0;
-    int n = 1;
-    for (PhyloNeighbor *nb : nei->node->neighbors)
-        if (nb->node != dad) n += countPending(nb, nei->node);
-    return n;
-}
-
-void PhyloTree::applyScaleFactors(const std::vector<PlanOp> &plan, const std::vector<double> &sum_scale) {
-    // dad_branch->lh_scale_factor = left + right (:157) + sum_scale (:395,477), in plan order
-    for (size_t k = 0; k < plan.size(); k++)
-        plan[k].dst->lh_scale_factor =
-            plan[k].left->lh_scale_factor + plan[k].right->lh_scale_factor + sum_scale[k];
-}
-
-iqhip_branch_end PhyloTree::branchEnd(PhyloNeighbor *nei) const {
-    iqhip_branch_end e;
-    e._pad = 0;
-    if (nei->node->isLeaf()) {
-        e.key = 0;
-        e.leaf = nei->node->id;
-    } else {
-        e.key = nei->partial_lh;
-        e.leaf = -1;
+    static void needEngine(Tree *t) {
+        if (!t->engine) throw std::runtime_error("HIP likelihood kernel selected but no engine attached");
     }
-    return e;
-}
+    static void updatePartials(Tree *t, Plan &plan, double *sum_scale) {
+        record(t, plan);
+        if (t->dry_run) return;
+        needEngine(t);
+        Base::updatePartials(t, plan, sum_scale);
+        t->num_submissions++;
+    }
+    static double traverseLnl(Tree *t, Plan &plan, iqhip_branch_end a, iqhip_branch_end b, double len, double *sum_scale) {
+        record(t, plan);
+        const int nops = (int)plan.ops.size();
+        if (t->dry_run) {
+            if (!t->allreduce_hook) return 0.0;
+            // CPU rehearsal of the caller-owned collective (tests, gloo): the hook receives a HOST vector laid out
+            // like the device result {lnl, -, sum_scale[k]...}, fills in this rank's share and all-reduces it; no
+            // likelihood arithmetic happens in this library.
+            std::vector<double> res(2 + plan.ops.size(), 0.0);
+            t->allreduce_hook(res.data(), (int)res.size(), t->allreduce_ctx);
+            for (int k = 0; k < nops; k++) sum_scale[k] = res[2 + k];
+            return res[0];
+        }
+        needEngine(t);
+        double lnl;
+        if (t->allreduce_hook) {  // caller-owned collective (the engine's own: iqhip_comm_init_rank / iqhip_create_sharded)
+            chk(t, iqhip_traverse_lnl_async(t->engine, plan.empty() ? nullptr : plan.ops.data(), nops, a, b, len),
+                "iqhip_traverse_lnl_async");
+            const int nres = 2 + nops;
+            t->allreduce_hook(iqhip_result_device_ptr(t->engine), nres, t->allreduce_ctx);
+            std::vector<double> res(nres);
+            chk(t, iqhip_result_read(t->engine, res.data(), nres), "iqhip_result_read");
+            lnl = res[0];
+            for (int k = 0; k < nops; k++) sum_scale[k] = res[2 + k];
+        } else {
+            lnl = Base::traverseLnl(t, plan, a, b, len, sum_scale);
+        }
+        t->num_submissions++;
+        return lnl;
+    }
+    static void computeTheta(Tree *t, iqhip_branch_end a, iqhip_branch_end b) {
+        if (t->dry_run) return;
+        needEngine(t);
+        Base::computeTheta(t, a, b);
+    }
+    static void derv(Tree *t, double len, double &df, double &ddf) {
+        t->num_derv_calls++;
+        if (t->dry_run) return;
+        needEngine(t);
+        if (t->allreduce_hook) {
+            chk(t, iqhip_derv_async(t->engine, len), "iqhip_derv_async");
+            t->allreduce_hook(iqhip_result_device_ptr(t->engine), 2, t->allreduce_ctx);
+            double res[2];
+            chk(t, iqhip_result_read(t->engine, res, 2), "iqhip_result_read");
+            df = res[0];
+            ddf = res[1];
+            if (isnan(df) || isinf(df)) df = ddf = 0.0;  // phylokernel.h:647-651
+        } else {
+            Base::derv(t, len, df, ddf);
+        }
+    }
+    static double lnlFromTheta(Tree *t, double len) {
+        if (t->dry_run) return 0.0;
+        needEngine(t);
+        return Base::lnlFromTheta(t, len);
+    }
+    static double optimizeBranch(Tree *t, Plan &plan, iqhip_branch_end a, iqhip_branch_end b, double xguess, int max_steps,
+                                 double *sum_scale, int *nsteps) {
+        record(t, plan);
+        needEngine(t);
+        const double optx = Base::optimizeBranch(t, plan, a, b, xguess, max_steps, sum_scale, nsteps);
+        t->num_submissions++;
+        t->num_derv_calls += *nsteps;
+        return optx;
+    }
+};
+
+iqhip_branch_end PhyloTree::branchEnd(PhyloNeighbor *nei) const { return iqhip_adapter::branchEnd<MirrorPolicy>(nei); }
 
 void PhyloTree::computePartialLikelihoodHIP(PhyloNeighbor *dad_branch, PhyloNode *dad) {
-    if (!central_partial_lh) initializeAllPartialLh();
-    std::vector<PlanOp> plan;
-    collectPlan(dad_branch, dad, plan);
-    last_plan = plan;
-    if (plan.empty()) return;
-    std::vector<double> sum_scale(plan.size(), 0.0);
-    if (!dry_run) {
-        if (!engine) throw std::runtime_error("HIP likelihood kernel selected but no engine attached");
-        pushInputs();
-        std::vector<iqhip_node_op> ops(plan.size());
-        for (size_t k = 0; k < plan.size(); k++) ops[k] = plan[k].op;
-        check(iqhip_update_partials(engine, ops.data(), (int)ops.size(), sum_scale.data()),
-              "iqhip_update_partials");
-        num_submissions++;
-    }
-    applyScaleFactors(plan, sum_scale);
+    MirrorPolicy::Plan plan;
+    iqhip_adapter::computePartialLikelihood<MirrorPolicy>(this, dad_branch, dad, &plan);
+    if (plan.empty()) last_plan.clear();
 }
 
 double PhyloTree::computeLikelihoodBranchHIP(PhyloNeighbor *dad_branch, PhyloNode *dad) {
-    PhyloNode *node = dad_branch->node;
-    PhyloNeighbor *node_branch = node->findNeighbor(dad);
-    if (!central_partial_lh) initializeAllPartialLh();
-    if (node->isLeaf()) {  // phylokernel.h:739-746
-        std::swap(dad, node);
-        std::swap(dad_branch, node_branch);
-    }
-    std::vector<PlanOp> plan;
-    if ((dad_branch->partial_lh_computed & 1) == 0) collectPlan(dad_branch, dad, plan);
-    if ((node_branch->partial_lh_computed & 1) == 0) collectPlan(node_branch, node, plan);
-    last_plan = plan;
-    std::vector<double> sum_scale(plan.size(), 0.0);
-    double lnl = 0.0;
-    if (dry_run && allreduce_hook) {
-        // CPU rehearsal of the sharded protocol (tests, gloo): the hook receives a HOST vector
-        // laid out like the device result {lnl, -, sum_scale[k]...}, fills in this rank's share
-        // and all-reduces it; no likelihood arithmetic happens in this library.
-        std::vector<double> res(2 + plan.size(), 0.0);
-        allreduce_hook(res.data(), (int)res.size(), allreduce_ctx);
-        lnl = res[0];
-        for (size_t k = 0; k < plan.size(); k++) sum_scale[k] = res[2 + k];
-    }
-    if (!dry_run) {
-        if (!engine) throw std::runtime_error("HIP likelihood kernel selected but no engine attached");
-        pushInputs();
-        std::vector<iqhip_node_op> ops(plan.size());
-        for (size_t k = 0; k < plan.size(); k++) ops[k] = plan[k].op;
-        // dad_branch points at `node`'s subtree; node_branch at `dad`'s (a leaf after the swap)
-        if (allreduce_hook) {
-            check(iqhip_traverse_lnl_async(engine, ops.data(), (int)ops.size(), branchEnd(node_branch),
-                                           branchEnd(dad_branch), dad_branch->length),
-                  "iqhip_traverse_lnl_async");
-            const int nres = 2 + (int)ops.size();
-            allreduce_hook(iqhip_result_device_ptr(engine), nres, allreduce_ctx);
-            std::vector<double> res(nres);
-            check(iqhip_result_read(engine, res.data(), nres), "iqhip_result_read");
-            lnl = res[0];
-            for (size_t k = 0; k < plan.size(); k++) sum_scale[k] = res[2 + k];
-        } else {
-            check(iqhip_traverse_lnl(engine, ops.data(), (int)ops.size(), branchEnd(node_branch),
-                                     branchEnd(dad_branch), dad_branch->length, sum_scale.data(), &lnl),
-                  "iqhip_traverse_lnl");
-        }
-        num_submissions++;
-    }
-    applyScaleFactors(plan, sum_scale);
-    return node_branch->lh_scale_factor + dad_branch->lh_scale_factor + lnl;  // :751
+    return iqhip_adapter::computeLikelihoodBranch<MirrorPolicy>(this, dad_branch, dad);
 }
 
 void PhyloTree::computeLikelihoodDervHIP(PhyloNeighbor *dad_branch, PhyloNode *dad, double &df, double &ddf) {
-    PhyloNode *node = dad_branch->node;
-    PhyloNeighbor *node_branch = node->findNeighbor(dad);
-    if (!central_partial_lh) initializeAllPartialLh();
-    if (node->isLeaf()) {  // phylokernel.h:491-498
-        std::swap(dad, node);
-        std::swap(dad_branch, node_branch);
-    }
-    if ((dad_branch->partial_lh_computed & 1) == 0) computePartialLikelihoodHIP(dad_branch, dad);
-    if ((node_branch->partial_lh_computed & 1) == 0) computePartialLikelihoodHIP(node_branch, node);
-    df = ddf = 0.0;
-    num_derv_calls++;
-    if (dry_run) { theta_computed = true; return; }
-    if (!engine) throw std::runtime_error("HIP likelihood kernel selected but no engine attached");
-    pushInputs();
-    if (!theta_computed) {  // :535-579
-        theta_computed = true;
-        check(iqhip_compute_theta(engine, branchEnd(node_branch), branchEnd(dad_branch)), "iqhip_compute_theta");
-    }
-    if (allreduce_hook) {
-        check(iqhip_derv_async(engine, dad_branch->length), "iqhip_derv_async");
-        allreduce_hook(iqhip_result_device_ptr(engine), 2, allreduce_ctx);
-        double res[2];
-        check(iqhip_result_read(engine, res, 2), "iqhip_result_read");
-        df = res[0];
-        ddf = res[1];
-        if (isnan(df) || isinf(df)) df = ddf = 0.0;  // phylokernel.h:647-651
-    } else {
-        check(iqhip_derv(engine, dad_branch->length, &df, &ddf), "iqhip_derv");
-    }
+    iqhip_adapter::computeLikelihoodDerv<MirrorPolicy>(this, dad_branch, dad, df, ddf);
 }
 
 double PhyloTree::computeLikelihoodFromBufferHIP() {
     assert(current_it && current_it_back);
-    if (!theta_computed) throw std::runtime_error("computeLikelihoodFromBuffer: theta not computed");
-    double lnl = 0.0;
-    if (!dry_run) {
-        if (!engine) throw std::runtime_error("HIP likelihood kernel selected but no engine attached");
-        check(iqhip_lnl_from_theta(engine, current_it->length, &lnl), "iqhip_lnl_from_theta");
-    }
-    return current_it->lh_scale_factor + current_it_back->lh_scale_factor + lnl;  // :1028
+    return iqhip_adapter::computeLikelihoodFromBuffer<MirrorPolicy>(this);
 }
 
 // =========================================================================================
@@ -762,29 +712,12 @@ void PhyloTree::optimizeOneBranch(PhyloNode *node1, PhyloNode *node2, bool clear
     double d2l;
     double optx;
     if (device_newton && engine && !dry_run && !allreduce_hook && n_unobserved == 0) {
-        // partials + theta exactly as the first computeFuncDerv of the host loop would make them
-        PhyloNeighbor *dad_branch = current_it, *node_branch = current_it_back;
-        PhyloNode *dad = current_it_back->node, *node = current_it->node;
-        if (node->isLeaf()) { std::swap(dad, node); std::swap(dad_branch, node_branch); }
-        if (!central_partial_lh) initializeAllPartialLh();
-        std::vector<PlanOp> plan;
-        if ((dad_branch->partial_lh_computed & 1) == 0) collectPlan(dad_branch, dad, plan);
-        if ((node_branch->partial_lh_computed & 1) == 0) collectPlan(node_branch, node, plan);
-        last_plan = plan;
-        pushInputs();
-        std::vector<iqhip_node_op> ops(plan.size());
-        for (size_t k = 0; k < plan.size(); k++) ops[k] = plan[k].op;
-        std::vector<double> sum_scale(plan.size() + 1, 0.0);
+        // one engine call: pending node updates of both ends + theta + the whole minimizeNewton solve (on a sharded
+        // engine as an enqueued chain of steps with an in-stream all-reduce each); allreduce_hook is the legacy
+        // caller-owned collective, which has to come back to the host between steps
         int nsteps = 0;
-        theta_computed = true;
-        check(iqhip_optimize_branch(engine, ops.empty() ? nullptr : ops.data(), (int)ops.size(),
-                                    branchEnd(node_branch), branchEnd(dad_branch), current_len, min_branch_length,
-                                    max_branch_length, min_branch_length, maxNRStep, sum_scale.data(), &optx, &d2l,
-                                    &nsteps),
-              "iqhip_optimize_branch");
-        applyScaleFactors(plan, sum_scale);
-        num_submissions++;
-        num_derv_calls += nsteps;
+        optx = iqhip_adapter::minimizeNewtonOnBranch<MirrorPolicy>(this, current_len, maxNRStep, &nsteps);
+        (void)d2l;
     } else {
         optx = minimizeNewton(min_branch_length, current_len, max_branch_length, min_branch_length, d2l, maxNRStep);
     }
@@ -949,23 +882,18 @@ void PhyloTree::computeAllPartialLh() {
     if (lh_mem_save != LM_ALL_BRANCH) throw std::runtime_error("computeAllPartialLh needs LM_ALL_BRANCH");
     if (!central_partial_lh) initializeAllPartialLh();
     // one plan for every pending directed vector (each has its own buffer in this mode), one submission
-    std::vector<PlanOp> plan;
+    MirrorPolicy::Plan plan;
     for (PhyloNode *node : nodes)
         for (PhyloNeighbor *nb : node->neighbors)
-            if (!nb->node->isLeaf() && (nb->partial_lh_computed & 1) == 0) collectPlan(nb, node, plan);
-    last_plan = plan;
+            if (!nb->node->isLeaf() && (nb->partial_lh_computed & 1) == 0)
+                iqhip_adapter::collectPlan<MirrorPolicy>(this, nb, node, plan);
+    MirrorPolicy::record(this, plan);
     if (plan.empty()) return;
+    if (!dry_run && allreduce_hook) throw std::runtime_error("computeAllPartialLh: not available with a caller-owned collective");
     std::vector<double> sum_scale(plan.size(), 0.0);
-    if (!dry_run) {
-        if (!engine) throw std::runtime_error("HIP likelihood kernel selected but no engine attached");
-        if (allreduce_hook) throw std::runtime_error("computeAllPartialLh: not available on a sharded tree");
-        pushInputs();
-        std::vector<iqhip_node_op> ops(plan.size());
-        for (size_t k = 0; k < plan.size(); k++) ops[k] = plan[k].op;
-        check(iqhip_update_partials(engine, ops.data(), (int)ops.size(), sum_scale.data()), "iqhip_update_partials");
-        num_submissions++;
-    }
-    applyScaleFactors(plan, sum_scale);
+    pushInputs();
+    MirrorPolicy::updatePartials(this, plan, sum_scale.data());
+    iqhip_adapter::applyScaleFactors<MirrorPolicy>(plan, sum_scale.data());
 }
 
 void PhyloTree::evaluateNNIsBatch(std::vector<NNIMove> &moves) {

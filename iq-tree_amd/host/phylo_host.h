@@ -62,11 +62,14 @@ struct PhyloNode {
     void clearAllPartialLh(bool make_null, PhyloNode *dad);  // phylonode.cpp:52-65
 };
 
-// a recorded node update (also what the CPU-only tests inspect in dry-run mode)
+// a recorded node update (also what the CPU-only tests inspect in dry-run mode); dst / left / right are NULL for
+// the intermediate products of a multifurcating node
 struct PlanOp {
     PhyloNeighbor *dst, *left, *right;
     iqhip_node_op op;
 };
+
+struct MirrorPolicy;  // phylo_host.cpp: this tree's answers to include/iqhip_adapter.h
 
 class PhyloTree {
 public:
@@ -202,6 +205,7 @@ public:
     long num_submissions = 0;
 
 private:
+    friend struct MirrorPolicy;
     ComputePartialLikelihoodType computePartialLikelihoodPointer = nullptr;
     ComputeLikelihoodBranchType computeLikelihoodBranchPointer = nullptr;
     ComputeLikelihoodFromBufferType computeLikelihoodFromBufferPointer = nullptr;
@@ -213,11 +217,9 @@ private:
     void computeLikelihoodDervHIP(PhyloNeighbor *dad_branch, PhyloNode *dad, double &df, double &ddf);
     double computeLikelihoodFromBufferHIP();
 
-    // plan building: the reference's recursion (phylokernel.h:70-157) with the pattern loop
-    // replaced by "append one op"
-    void collectPlan(PhyloNeighbor *dad_branch, PhyloNode *dad, std::vector<PlanOp> &plan);
-    void applyScaleFactors(const std::vector<PlanOp> &plan, const std::vector<double> &sum_scale);
-    int countPending(PhyloNeighbor *nei, PhyloNode *dad) const;
+    // plan building, flag handling, re-orientation, scale-factor bookkeeping and the bodies of the four kernels are
+    // include/iqhip_adapter.h instantiated with MirrorPolicy -- the same templates integration/phylotree_hip.cpp
+    // instantiates with the reference's types
     iqhip_branch_end branchEnd(PhyloNeighbor *nei) const;
     void check(int rc, const char *what) const;
     void pushInputs();

@@ -121,6 +121,24 @@ def random_tree_newick(ntaxa, seed, lo=0.02, hi=0.2, caterpillar=False):
     return "(%s:%.6f,%s:%.6f,%s:%.6f);" % (items[0], l[0], items[1], l[1], items[2], l[2])
 
 
+def random_multifurcating_newick(ntaxa, seed, lo=0.02, hi=0.2, max_children=5, p_multi=0.4):
+    """Random unrooted tree with polytomies (user trees of `-t` / `-te`, consensus trees): random joining where a join
+    takes 3..max_children items with probability p_multi, else 2."""
+    rng = np.random.default_rng(seed)
+    items = [str(i) for i in range(ntaxa)]
+    while len(items) > 3:
+        k = 2
+        if rng.random() < p_multi:
+            k = int(rng.integers(3, max_children + 1))
+        k = min(k, len(items) - 2)
+        if k < 2:
+            break
+        idx = sorted(rng.choice(len(items), k, replace=False))
+        parts = ["%s:%.6f" % (items[i], rng.uniform(lo, hi)) for i in idx]
+        items = [x for q, x in enumerate(items) if q not in idx] + ["(" + ",".join(parts) + ")"]
+    return "(" + ",".join("%s:%.6f" % (x, rng.uniform(lo, hi)) for x in items) + ");"
+
+
 def parse_newick(s):
     """-> nested (label, length, children) tuples; minimal parser for the generator's output."""
     pos = [0]

@@ -553,3 +553,78 @@ float oracle_dot_float8(const float *x, const float *y, size_t n) {
     volatile float ab = a + b, cd = c + d;
     return ab + cd;
 }
+
+/* Multifurcating node, the reference's SCALAR kernel (phylotreesse.cpp:609-806; the SIMD kernels hand nodes of
+ * degree > 3 to it, phylokernel.h:73-77): per pattern the product over ALL children of (E_child * child) in
+ * probability space (plain running sums, not the lane-strided ones), then U^-1, then ONE scaling test with the
+ * scalar kernel's rule: lh_max == 0 -> copy the unknown tip vector, count += 4 (phylotreesse.cpp:776-788), else
+ * if ptn_invar == 0 multiply by 2^256, count += 1.  scale_num starts at the sum over the internal children.
+ * child k: states_k != NULL -> leaf (state bytes), else plh_k / sc_k; returns this node's own sum_scale. */
+double oracle_partial_update_multi(int n, int ncat, size_t nptn, int nchild, const double *eval, const double *evec,
+                                   const double *inv_evec, const double *rates, const double *tip, int state_unknown,
+                                   const uint8_t *const *states, const double *const *plh, const short *const *sc,
+                                   const double *lens, const double *ptn_freq, const double *ptn_invar,
+                                   double *out, short *out_scale) {
+    const int block = n * ncat;
+    double *E = (double *)malloc(sizeof(double) * (size_t)nchild * block * n);
+    for (int k = 0; k < nchild; k++) oracle_echild(n, ncat, eval, evec, rates, lens[k], E + (size_t)k * block * n);
+    double sum_scale = 0.0;
+#ifdef _OPENMP
+#pragma omp parallel for reduction(+ : sum_scale) schedule(static)
+#endif
+    for (size_t ptn = 0; ptn < nptn; ptn++) {
+        double all[block];
+        for (int i = 0; i < block; i++) all[i] = 1.0;
+        int cnt = 0;
+        for (int k = 0; k < nchild; k++) {
+            const double *Ek = E + (size_t)k * block * n;
+            if (states[k]) {
+                const int s = states[k][ptn];
+                for (int c = 0; c < ncat; c++)
+                    for (int x = 0; x < n; x++) {
+                        double v = 1.0; /* STATE_UNKNOWN row (phylotreesse.cpp:677-681) */
+                        if (s != state_unknown) {
+                            v = 0.0;
+                            for (int i = 0; i < n; i++) v += Ek[(size_t)c * n * n + x * n + i] * tip[(size_t)s * n * g_nclass + TIPIDX(c * n + i)];
+                        }
+                        all[c * n + x] *= v;
+                    }
+            } else {
+                cnt += sc[k][ptn];
+                const double *ch = plh[k] + ptn * block;
+                for (int c = 0; c < ncat; c++)
+                    for (int x = 0; x < n; x++) {
+                        double v = 0.0;
+                        for (int i = 0; i < n; i++) v += Ek[(size_t)c * n * n + x * n + i] * ch[c * n + i];
+                        all[c * n + x] *= v;
+                    }
+            }
+        }
+        double *o = out + ptn * block;
+        double lh_max = 0.0;
+        for (int c = 0; c < ncat; c++) {
+            const double *ie = inv_evec + (size_t)CLS(c) * n * n;
+            for (int i = 0; i < n; i++) {
+                double r = 0.0;
+                for (int x = 0; x < n; x++) r += all[c * n + x] * ie[i * n + x];
+                o[c * n + i] = r;
+                if (fabs(r) > lh_max) lh_max = fabs(r);
+            }
+        }
+        if (lh_max < SCALING_THRESHOLD) {
+            if (lh_max == 0.0) {
+                for (int c = 0; c < ncat; c++)
+                    for (int i = 0; i < n; i++) o[c * n + i] = tip[(size_t)state_unknown * n * g_nclass + TIPIDX(c * n + i)];
+                sum_scale += LOG_SCALING_THRESHOLD * 4 * ptn_freq[ptn];
+                cnt += 4;
+            } else if (ptn_invar[ptn] == 0.0) {
+                for (int i = 0; i < block; i++) o[i] *= SCALING_THRESHOLD_INVER;
+                sum_scale += LOG_SCALING_THRESHOLD * ptn_freq[ptn];
+                cnt += 1;
+            }
+        }
+        out_scale[ptn] = (short)cnt;
+    }
+    free(E);
+    return sum_scale;
+}

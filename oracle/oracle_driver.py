@@ -47,6 +47,9 @@ def lib():
     L.oracle_partial_update.argtypes = [C.c_int, C.c_int, C.c_size_t, dp, dp, dp, dp, dp, C.c_int,
                                         u8, dp, sp, C.c_double, u8, dp, sp, C.c_double, dp, dp, dp, sp]
     L.oracle_partial_update.restype = C.c_double
+    L.oracle_partial_update_multi.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_int, dp, dp, dp, dp, dp, C.c_int,
+                                              C.POINTER(u8), C.POINTER(dp), C.POINTER(sp), dp, dp, dp, dp, sp]
+    L.oracle_partial_update_multi.restype = C.c_double
     L.oracle_branch_lnl.argtypes = [C.c_int, C.c_int, C.c_size_t, dp, dp, dp, C.c_double, dp, u8, dp, dp,
                                     dp, dp, dp]
     L.oracle_branch_lnl.restype = C.c_double
@@ -266,7 +269,11 @@ class OracleTree:
         self._ctx()
         assert not self.is_leaf(to)
         kids = [(nb, ln) for nb, ln in self.adj[to] if nb != frm]
-        assert len(kids) == 2, "oracle handles bifurcating nodes only"
+        if len(kids) > 2:  # multifurcating node: the reference's scalar kernel (phylotreesse.cpp:702-806)
+            res = self._partial_multi(to, kids)
+            self.cache[key] = res
+            return res
+        assert len(kids) == 2
         (l, ll), (r, rl) = kids
         if not self.is_leaf(l) and self.is_leaf(r):
             (l, ll), (r, rl) = (r, rl), (l, ll)
@@ -283,6 +290,21 @@ class OracleTree:
         res = (out, sc, args_l[3] + args_r[3] + sum_scale)
         self.cache[key] = res
         return res
+
+    def _partial_multi(self, to, kids):
+        args = [self._child(to, k) for k, _ in kids]
+        nk = len(kids)
+        u8, dp, sp = C.POINTER(C.c_uint8), C.POINTER(C.c_double), C.POINTER(C.c_short)
+        st = (u8 * nk)(*[_u8(a[0]) if a[0] is not None else u8() for a in args])
+        pl = (dp * nk)(*[_dp(a[1]) if a[1] is not None else dp() for a in args])
+        sc = (sp * nk)(*[_sp(a[2]) if a[2] is not None else sp() for a in args])
+        lens = np.array([ln for _, ln in kids], dtype=np.float64)
+        out = np.empty((self.nptn, self.block))
+        osc = np.empty(self.nptn, dtype=np.int16)
+        sum_scale = self.L.oracle_partial_update_multi(
+            self.n, self.ncat, self.nptn, nk, _dp(self.eval), _dp(self.evec), _dp(self.inv_evec), _dp(self.rates),
+            _dp(self.tip), self.su, st, pl, sc, _dp(lens), _dp(self.freq), _dp(self.invar), _dp(out), _sp(osc))
+        return (out, osc, sum(a[3] for a in args) + sum_scale)
 
     def _child(self, node, child):
         if self.is_leaf(child):

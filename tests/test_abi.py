@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported(pkg):
 
 
 def test_struct_layout_matches_header(pkg):
-    assert C.sizeof(pkg.NodeOp) == 48
+    assert C.sizeof(pkg.NodeOp) == 56
     assert C.sizeof(pkg.BranchEnd) == 16
 
 

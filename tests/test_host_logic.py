@@ -134,10 +134,23 @@ def test_tip_partial_lh_table(pkg, synth, oracle):
     np.testing.assert_array_equal(tip.reshape(-1), ot.tip)
 
 
-def test_multifurcation_is_refused(pkg, synth):
-    t = pkg.PhyloTree("((0:0.1,1:0.1,2:0.1):0.1,3:0.1,4:0.1);")
-    t.set_alignment(4, 0, np.zeros((5, 4), dtype=np.uint8), np.ones(4))
+def test_multifurcating_node_becomes_a_chain_of_binary_updates(pkg, synth):
+    """degree > 3 (the reference's scalar kernel, phylotreesse.cpp:702-806): the product over all children is carried
+    through intermediate vectors over zero-length branches that are never rescaled; only the node's own update tests
+    for underflow."""
+    t = pkg.PhyloTree("((0:0.1,1:0.2,2:0.3,5:0.35):0.4,3:0.1,4:0.1);")
+    t.set_alignment(4, 0, np.zeros((6, 4), dtype=np.uint8), np.ones(4))
     t.set_model(synth.gtr_model())
     t.set_dry_run(True)
-    with pytest.raises(pkg.HostError):
-        t.compute_likelihood()
+    t.compute_likelihood()
+    plan = t.last_plan()
+    multi = [p for p in plan if p["flags"] & 1]
+    assert len(plan) == 4 and len(multi) == 2          # 2 internal nodes; the 4-child one takes 3 updates
+    k = plan.index(multi[0])
+    a, b, c = plan[k], plan[k + 1], plan[k + 2]
+    assert (a["left_leaf"], a["right_leaf"]) == (0, 1) and (a["left_len"], a["right_len"]) == (0.1, 0.2)
+    assert a["dst"][1] == -1 and b["dst"][1] == -1 and c["dst"][1] != -1      # only the last one answers a neighbour
+    assert b["left_key"] == a["dst_key"] and b["left_len"] == 0.0 and b["right_leaf"] == 2 and b["flags"] == 1
+    assert c["left_key"] == b["dst_key"] and c["left_len"] == 0.0 and c["right_leaf"] == 5 and c["flags"] == 0
+    assert a["dst_key"] >> 63 == 1 and b["dst_key"] >> 63 == 1 and a["dst_key"] != b["dst_key"]
+    assert c["dst_key"] >> 63 == 0

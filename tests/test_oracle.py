@@ -164,3 +164,27 @@ def test_oracle_ascertainment_bias_correction(synth, oracle, n, ncat, seq_type, 
         h = 1e-5
         np.testing.assert_allclose(df, (f(t + h) - f(t - h)) / (2 * h), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(ddf, (f(t + h) - 2 * f(t) + f(t - h)) / h ** 2, rtol=2e-3)
+
+
+@pytest.mark.parametrize("n,ncat,seq_type", [(4, 4, 0), (20, 2, 1)])
+def test_oracle_multifurcating_nodes_match_textbook(synth, oracle, n, ncat, seq_type):
+    """degree > 3: the restatement of the reference's scalar kernel (phylotreesse.cpp:702-806) against the
+    probability-space recursion, which handles any degree."""
+    import textbook
+    model = synth.gtr_model(ncat=ncat) if n == 4 else synth.random_reversible_model(n, 4, alpha=0.7, ncat=ncat)
+    su = oracle.state_unknown_for(n, seq_type)
+    nwk = synth.random_multifurcating_newick(15, 8, max_children=5, p_multi=0.6)
+    assert max(nwk.count(","), 0) > 0
+    st = synth.simulate_alignment(nwk, model, 200, 9, 0.05, su)
+    pat, freq = synth.compress_patterns(st)
+    tree = oracle.OracleTree(nwk, n, seq_type, pat, freq, None, model)
+    assert max(len(v) for v in tree.adj.values()) > 3
+    site = textbook.site_log_likelihoods(tree.adj, pat, model, seq_type, su)
+    ref = float((site * freq).sum())
+    lnl, (a, b) = tree.likelihood()
+    assert abs(lnl - ref) <= 1e-9 * abs(ref)
+    # pulley principle over all branches, including those at the polytomies
+    for x in tree.adj:
+        for y, _ in tree.adj[x]:
+            if x < y:
+                assert abs(tree.branch_lnl(x, y)[0] - ref) <= 1e-9 * abs(ref)
