@@ -1363,7 +1363,18 @@ extern "C" int iqhip_optimize_branch_batch(iqhip_engine *e, const iqhip_branch_t
     const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(3, (size_t)(150 * 1024) / newton_lds));
     const int capacity = e->num_cus * wg_per_cu;
     const int wgs_needed = (int)std::max<int64_t>(1, (e->ntiles + 3) / 4);
-    const int chunk = std::min(ntasks, capacity);             // tasks per launch
+    int chunk = std::min(ntasks, capacity);             // tasks per launch
+    {   // every task of a launch owns a theta buffer: keep them within a quarter of the free device memory and
+        // run larger batches in several launches (protein+G4 at 50k patterns: 32 MB per task)
+        size_t free_b = 0, total_b = 0;
+        const size_t per_task = (size_t)e->nptn_pad * e->block * sizeof(double);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t have = e->theta_batch_cap * sizeof(double);
+            const size_t room = (free_b + have) / 4;
+            const size_t fit = std::max<size_t>(1, room / std::max<size_t>(1, per_task));
+            if ((size_t)chunk > fit) chunk = (int)fit;
+        }
+    }
     const int G = std::max(1, std::min(wgs_needed, capacity / chunk));
     const size_t theta_stride = (size_t)e->nptn_pad * e->block;
     if ((size_t)chunk * theta_stride > e->theta_batch_cap) {
@@ -1424,7 +1435,17 @@ extern "C" int iqhip_optimize_branch_batch(iqhip_engine *e, const iqhip_branch_t
             r.nsteps = (int)o[2];
             r.status = (int)o[3];
             r.lnl = o[4];
-            if (r.status == 4) return fail(IQHIP_ERR_HIP, "iqhip_optimize_branch_batch: grid barrier timed out");
+            if (r.status == 4) {
+                // the task's grid barrier gave up (its workgroups were not co-resident): redo this one task with the
+                // barrier-free chain form -- its node updates have run, so only theta + the solve + lnL remain
+                const iqhip_branch_task &k = tasks[first + t];
+                (void)hipStreamSynchronize(e->stream);
+                rc = iqhip_compute_theta(e, k.a, k.b);
+                if (!rc) rc = newton_chain(e, k.xguess, k.x1, k.x2, k.xacc, k.max_steps, &r.optx, &r.d2l, &r.nsteps);
+                if (!rc) rc = iqhip_lnl_from_theta(e, r.optx, &r.lnl);
+                if (rc) return rc;
+                r.status = 0;
+            }
         }
     }
     if (total_ops > 0) {

@@ -11,9 +11,51 @@
 // bounded spin) with one workgroup per CU.
 #include <string.h>
 
+#include <mutex>
+
 #include "iqhip_internal.h"
 
 namespace iqhip {
+
+// Kernels with a hand-rolled grid barrier (k_newton, k_newton_batch) need all their workgroups resident at once.
+// Their grids are sized for that on an otherwise free chip, and ordinary kernels of other engines only delay them
+// (those finish without waiting for anybody).  What must never happen is TWO barrier kernels of different engines
+// (partition analyses drive one engine per host thread, phylosupertree.cpp:970) each holding part of the CUs while
+// waiting for workgroups that cannot be scheduled.  So barrier kernels of one device are chained: each launch waits
+// (hipStreamWaitEvent, device side, no host stall) for the previous barrier kernel of ANY engine on that device.
+// The barriers use relaxed agent-scope atomics + s_waitcnt vmcnt(0) for the hand-off of the partial sums, which is
+// outside the HIP memory model proper; it is the R2 "sc1 loads and stores both sides" form measured for gfx950 in
+// MI355X_MICROARCH.md (Workgroup dispatch, valid forms).  A barrier that still times out reports status 4 and the
+// engine finishes the solve with the barrier-free chain form.
+namespace {
+struct BarrierChain {
+    std::mutex mu;
+    hipEvent_t ev[64] = {};
+    bool valid[64] = {};
+};
+BarrierChain &barrier_chain() {
+    static BarrierChain c;
+    return c;
+}
+struct BarrierLaunchGuard {
+    int dev;
+    hipStream_t stream;
+    bool active;
+    BarrierLaunchGuard(iqhip_engine *e, bool multi_wg) : dev(e->device), stream(e->stream), active(multi_wg && e->device < 64) {
+        if (!active) return;
+        BarrierChain &c = barrier_chain();
+        c.mu.lock();
+        if (c.valid[dev]) (void)hipStreamWaitEvent(stream, c.ev[dev], 0);
+    }
+    ~BarrierLaunchGuard() {
+        if (!active) return;
+        BarrierChain &c = barrier_chain();
+        if (!c.ev[dev] && hipEventCreateWithFlags(&c.ev[dev], hipEventDisableTiming) != hipSuccess) c.ev[dev] = nullptr;
+        if (c.ev[dev]) c.valid[dev] = hipEventRecord(c.ev[dev], stream) == hipSuccess;
+        c.mu.unlock();
+    }
+};
+}  // namespace
 
 struct NewtonArgs {
     const double *theta;
@@ -196,7 +238,7 @@ __global__ __launch_bounds__(256) void k_newton(const NewtonArgs A) {
                 long spins = 0;
                 while (__hip_atomic_load(A.barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > 50000000L) { s_fail = 1; break; }  // never hang the GPU
+                    if (++spins > 4000000L) { s_fail = 1; break; }  // never hang the GPU (~0.2 s)
                 }
             }
             __syncthreads();
@@ -343,7 +385,7 @@ __global__ __launch_bounds__(256) void k_newton_batch(const NewtonBatchArgs P) {
                 long spins = 0;
                 while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > 50000000L) { s_fail = 1; break; }  // never hang the GPU
+                    if (++spins > 4000000L) { s_fail = 1; break; }  // never hang the GPU (~0.2 s)
                 }
             }
             __syncthreads();
@@ -480,6 +522,7 @@ hipError_t launch_newton_batch(iqhip_engine *e, const void *d_tasks, int ntasks,
     P.out = out;
     P.G = G;
     const size_t lds = (size_t)(3 * e->block + 8) * sizeof(double);
+    BarrierLaunchGuard guard(e, G > 1);
     hipLaunchKernelGGL(k_newton_batch, dim3((unsigned)(ntasks * G)), dim3(256), lds, e->stream, P);
     return hipGetLastError();
 }
@@ -558,6 +601,7 @@ hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, d
     A.barrier_next = e->d_newton_barrier + ((e->newton_launches + 1) & 1);
     e->newton_launches++;
     const size_t lds = (size_t)(3 * e->block + 8) * sizeof(double);
+    BarrierLaunchGuard guard(e, grid > 1);
     hipLaunchKernelGGL(k_newton, dim3(grid), dim3(256), lds, e->stream, A);
     return hipGetLastError();
 }

@@ -52,3 +52,52 @@ def test_engines_on_concurrent_host_threads(pkg, synth, oracle):
     for i, vals in enumerate(out):
         assert all(v == seq[i] for v in vals)          # same numbers as the single-threaded run, every time
     print("8 partitions x %d evaluations: one thread %.2f ms, eight threads %.2f ms" % (reps, t_seq * 1e3, t_par * 1e3))
+
+
+def test_multi_workgroup_newton_solves_of_two_engines_overlap(pkg, synth, oracle):
+    """Two >= 100 000-pattern trees (grid-barrier Newton kernels with one workgroup per CU each) optimised from two
+    host threads at once, plus batched NNI evaluations: barrier kernels of different engines are chained per device
+    (kernels_newton.hip, BarrierLaunchGuard), so neither can strand the other's workgroups; results equal the
+    single-threaded ones."""
+    trees = []
+    for k in range(2):
+        t, ot, *_ = make_case(synth, oracle, pkg, 10, 110000, 4, 4, 9950 + k, mem_mode=pkg.LM_ALL_BRANCH)
+        assert t.nptn >= 100000
+        t.compute_likelihood()
+        trees.append(t)
+    edges = [[(a, b) for a in range(t.num_nodes) for b, _ in t.neighbors(a) if a < b] for t in trees]
+    lens0 = [[t.neighbor_info(a, b)["length"] for (a, b) in edges[i]] for i, t in enumerate(trees)]
+
+    def sweep(i, out):
+        t = trees[i]
+        for (a, b), ln in zip(edges[i], lens0[i]):      # same starting tree for every sweep
+            t.set_branch_length(a, b, ln, clear_reverse=False)
+        t.clear_all_partial_lh()
+        vals = []
+        for rep in range(3):
+            for (a, b) in edges[i]:
+                t.set_branch_length(a, b, 0.05 + 0.01 * rep, clear_reverse=True)
+                vals.append(t.optimize_one_branch(a, b))
+            vals.append(max(m["newloglh"] for m in t.evaluate_nnis_batch()))
+        out[i] = vals
+
+    seq = [None, None]
+    for i in range(2):
+        sweep(i, seq)
+    par = [None, None]
+    errs = []
+
+    def work(i):
+        try:
+            sweep(i, par)
+        except Exception as e:  # noqa
+            errs.append((i, repr(e)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    for i in range(2):
+        np.testing.assert_allclose(par[i], seq[i], rtol=1e-12)
