@@ -96,6 +96,8 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
         int v = atoi(kb);
         if (v >= 8 && v <= 150) e->lds_budget_bytes = v * 1024;
     }
+    e->leaf_tables = e->mfma_pipelined_ok;
+    if (const char *lt = getenv("IQHIP_LEAF_TABLES")) e->leaf_tables = e->mfma_pipelined_ok && atoi(lt) != 0;
     if (const char *wg = getenv("IQHIP_WG")) {
         int v = atoi(wg);
         if (v == 64 || v == 128 || v == 256) e->wg_size = v;
@@ -181,7 +183,7 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
         if (s.sc) hipFree(s.sc);
     }
     void *ptrs[] = {e->d_states, e->d_freq, e->d_invar, e->d_model, e->d_ops, e->d_slab,
-                    e->d_theta, e->d_pattern_lh, e->dummy.plh, e->dummy.sc, e->d_newton_partials,
+                    e->d_theta, e->d_pattern_lh, e->d_leaf_tab, e->dummy.plh, e->dummy.sc, e->d_newton_partials,
                     e->d_newton_barrier, e->d_ptn_scaled, e->d_boot, e->d_img, e->d_theta_batch, e->d_batch_partials,
                     e->d_batch_out, e->d_batch_barriers, e->d_batch_tasks};
     for (void *p : ptrs)
@@ -690,6 +692,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         d.pf = d.ld = e->dummy.plh;
         d.pf_sc = d.ld_sc = e->dummy.sc;
         d.sl = d.sr = e->d_states;
+        d.tabL = d.tabR = e->d_leaf_tab;
     };
     for (int k = 0; k < nops; k++) {
         const iqhip_node_op &o = ops[order[k]];
@@ -774,6 +777,33 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
             }
             producer[d.dst] = k;
         }
+    }
+    // K2 tables of the leaf children (pipelined matrix-core kernels): one slot per (op, leaf side), filled by
+    // k_leaf_tables before the traversal kernel of this submission
+    e->plan_nleaf_tabs = 0;
+    if (e->mfma && e->mfma_pipelined && e->leaf_tables) {
+        int ntab = 0;
+        for (int k = 0; k < nops; k++)
+            ntab += (e->h_ops[k].left_kind == CHILD_LEAF) + (e->h_ops[k].right_kind == CHILD_LEAF);
+        const size_t per = leaf_table_doubles(e);
+        const size_t need = std::max<size_t>(1, (size_t)ntab) * per;
+        if (need > e->leaf_tab_cap) {
+            HIPCHK(hipStreamSynchronize(e->stream));
+            if (e->d_leaf_tab) hipFree(e->d_leaf_tab);
+            e->d_leaf_tab = nullptr;
+            e->leaf_tab_cap = 0;
+            HIPCHK(dmalloc(&e->d_leaf_tab, need * 2));
+            e->leaf_tab_cap = need * 2;
+            e->uploaded_plan.clear();
+        }
+        int slot = 0;
+        for (int k = 0; k < nops; k++) {
+            DevOp &d = e->h_ops[k];
+            d.tabL = d.tabR = e->d_leaf_tab;
+            if (d.left_kind == CHILD_LEAF) d.tabL = e->d_leaf_tab + (size_t)(slot++) * per;
+            if (d.right_kind == CHILD_LEAF) d.tabR = e->d_leaf_tab + (size_t)(slot++) * per;
+        }
+        e->plan_nleaf_tabs = ntab;
     }
     for (int q = 0; q < kSentinels; q++) dummy_op(e->h_ops[nops + q]);  // targets of the look-ahead requests
     *last_dst = prev_dst;
@@ -897,6 +927,7 @@ static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, 
     rc = ensure_slab_rows(e, 2 + nops);
     if (rc) return rc;
     const int nwaves = (int)e->ntiles * e->lane_split;  // columns of the wave-partial slab
+    if (e->plan_nleaf_tabs > 0) HIPCHK(launch_leaf_tables(e, nops));
     timing_begin(e);
     const int *table = reinterpret_cast<const int *>(e->d_ops + e->plan_table_off);
     if (e->plan_nunits > 0) {  // stage 1: the independent subtrees, one set of workgroups each

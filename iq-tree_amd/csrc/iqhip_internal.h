@@ -52,6 +52,11 @@ struct __attribute__((aligned(16))) DevOp {
     int32_t push_hold;  // 1: copy this op's result into the HOLD registers (consumed by a CHILD_HOLD)
     int32_t out_row;    // row of the caller's op list this op answers (sum_scale[out_row]); plans may be reordered
     int32_t no_scale;   // IQHIP_OP_NO_SCALE: intermediate product of a multifurcating node, never rescaled
+    // matrix-core kernels: transition tables of the LEAF children (K2, phylokernel.h:187-232,293-317), built per
+    // submission by k_leaf_tables into an L2-resident buffer: tab[c][state][n] (n permuted to the accumulator
+    // image, see kernels_mfma.hip leaf_tab_pos); dummy-valid for non-leaf children
+    const double *tabL;
+    const double *tabR;
 };
 
 // Root branch descriptor for the lnL / theta kernels.
@@ -190,6 +195,10 @@ struct iqhip_engine {
     double *d_slab = nullptr;   // wave partials [nvals][nwaves]
     int64_t slab_cap = 0;
     double *d_theta = nullptr, *d_pattern_lh = nullptr;
+    double *d_leaf_tab = nullptr;   // K2 tables of the current plan's leaf children (matrix-core pipelined kernels)
+    size_t leaf_tab_cap = 0;        // doubles
+    int plan_nleaf_tabs = 0;        // tables the current plan needs (0: kernel variant without tables)
+    bool leaf_tables = false;       // IQHIP_LEAF_TABLES (default on for the pipelined matrix-core kernels)
     // Mixture models (phylokernelmixture.h, phylokernelmixrate.h): the ncat categories are (class, rate)
     // components; category c uses eigen-system cat_class[c].  Per-category expansions for the kernels
     // that are generic in (n, ncat): evalc[c][i], tipc[state][c][i]; per-class MFMA A images for the
@@ -346,6 +355,8 @@ void newton_task_fill(void *dst, const DevBranch &br, double xguess, double x1, 
 
 // kernels_mfma.hip (nstates 20 / 64)
 hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs, int nwaves);
+hipError_t launch_leaf_tables(iqhip_engine *e, int nops);  // K2 tables of every leaf child of d_ops[0..nops)
+size_t leaf_table_doubles(const iqhip_engine *e);          // doubles per (leaf child) table: ncat * state_unknown * n
 int mfma2_fixed_lds_doubles(int n);
 // mode 0: branch lnL, 1: theta, 2: df/ddf from theta, 3: lnL from theta
 hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, double len, int nwaves,

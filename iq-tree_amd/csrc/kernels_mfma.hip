@@ -22,6 +22,8 @@
 // This first version reads both children from memory (L2/MALL-resident after an earlier op of
 // the same launch); keeping the previous result in registers as in the DNA kernel is the next
 // optimisation step.
+#include <type_traits>
+
 #include "iqhip_internal.h"
 
 namespace iqhip {
@@ -223,6 +225,74 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------
+// K2 for the matrix-core kernels (phylokernel.h:187-232, 293-317): a LEAF child contributes, per category, the column
+// P_c(t)[:, state] = sum_i U[x][i] exp(eval_i r_c t) U^-1[i][state] of its branch's transition matrix -- a table
+// look-up by the pattern's state in the reference, 0 flops per pattern.  k_leaf_tables builds, per submission, one
+// table per (op, leaf side): tab[c][state][pos(x)], state < STATE_UNKNOWN (ambiguity states use their tip vectors,
+// the unknown state is a select of exactly 1.0 in the kernel, phylokernel.h:228-232), with the reference's own
+// association (E = U*ex rounded, then lane-strided unfused sums, (l0+l1)+(l2+l3)), so a leaf child's values are the
+// oracle's bit for bit.  The tables (codon: 32 KB, protein+G4: 15 KB per leaf branch) stay L2-resident; the traversal
+// kernels read a pattern's row straight into the accumulator image of the product that the matrix pipe no longer has
+// to compute: 50 of the 97 child products of a 50-taxon traversal.
+// pos(x): row x of an M-tile sits in accumulator register r = (x%16)/4 of lane group g = x%4, so a lane's four
+// registers are made contiguous: pos = 16*(x/16) + 4*(x%4) + (x%16)/4; the 4 tail rows of N = 20 keep their place.
+// ---------------------------------------------------------------------------------------
+__host__ __device__ inline int leaf_tab_pos(int x, int n) {
+    const int full = (n / 16) * 16;
+    if (x >= full) return x;
+    const int w = x & 15;
+    return (x & ~15) + 4 * (w & 3) + (w >> 2);
+}
+
+__global__ __launch_bounds__(256) void k_leaf_tables(const DevOp *ops, int n, int ncat, int nstate_rows,
+                                                     const double *__restrict__ eval, const double *__restrict__ evec,
+                                                     const double *__restrict__ rates, const double *__restrict__ tip) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int k = blockIdx.x / (2 * ncat), r = blockIdx.x - k * 2 * ncat, side = r / ncat, c = r - side * ncat;
+    const DevOp &d = ops[k];
+    if ((side ? d.right_kind : d.left_kind) != CHILD_LEAF) return;
+    const double len = side ? d.right_len : d.left_len;
+    double *tab = const_cast<double *>(side ? d.tabR : d.tabL) + (size_t)c * nstate_rows * n;
+    const int ld = n + 1;                 // padded rows: lanes walk different x
+    double *sE = smem;                    // [n][n+1]  E[x][i] = U[x][i] * exp(eval_i r_c t), rounded (K1, :159-181)
+    double *sTip = smem + n * ld;         // [nstate_rows][n]
+    for (int t = threadIdx.x; t < n * n; t += 256) {
+        const int x = t / n, i = t - x * n;
+        sE[x * ld + i] = __dmul_rn(evec[x * n + i], exp(eval[i] * (rates[c] * len)));
+    }
+    for (int t = threadIdx.x; t < nstate_rows * n; t += 256) sTip[t] = tip[t];
+    __syncthreads();
+    for (int t = threadIdx.x; t < nstate_rows * n; t += 256) {
+        const int s = t / n, x = t - s * n;
+        const double *a = sE + x * ld, *b = sTip + s * n;
+        double l0 = __dmul_rn(a[0], b[0]), l1 = __dmul_rn(a[1], b[1]), l2 = __dmul_rn(a[2], b[2]), l3 = __dmul_rn(a[3], b[3]);
+        for (int i = 4; i < n; i += 4) {
+            l0 = __dadd_rn(__dmul_rn(a[i], b[i]), l0);
+            l1 = __dadd_rn(__dmul_rn(a[i + 1], b[i + 1]), l1);
+            l2 = __dadd_rn(__dmul_rn(a[i + 2], b[i + 2]), l2);
+            l3 = __dadd_rn(__dmul_rn(a[i + 3], b[i + 3]), l3);
+        }
+        tab[(size_t)s * n + leaf_tab_pos(x, n)] = __dadd_rn(__dadd_rn(l0, l1), __dadd_rn(l2, l3));
+    }
+}
+
+size_t leaf_table_doubles(const iqhip_engine *e) { return (size_t)e->ncat * e->state_unknown * e->n; }
+
+hipError_t launch_leaf_tables(iqhip_engine *e, int nops) {
+    if (nops <= 0) return hipSuccess;
+    const int n = e->n, rows = e->state_unknown;
+    const size_t lds = (size_t)(n * (n + 1) + rows * n) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_tables), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_leaf_tables, dim3((unsigned)(nops * 2 * e->ncat)), dim3(256), lds, e->stream, e->d_ops, n, e->ncat,
+                       rows, e->d_eval, e->d_evec, e->d_rates, e->d_tip);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
 // Pipelined variant (compile-time category count).  Differences from k_traverse_mfma:
 //   * the previous op's result stays in registers: its accumulator image IS the B operand of
 //     the next op (CHILD_PREV), consumed and overwritten in place category by category;
@@ -236,7 +306,8 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
 // CS > 1 (category split): the CS waves of a workgroup share ONE tile and own C = ncat/CS categories each, so a
 // small alignment yields CS times the waves with 1/CS of the dependent MFMA chain per op; the only cross-wave step is
 // the scaling maximum of a pattern (LDS + one workgroup barrier per op).
-template <int N, int C, int WG, int CS = 1>
+// TAB: LEAF children are table look-ups (k_leaf_tables) instead of U * (ex .* tip) products on the matrix pipe.
+template <int N, int C, int WG, int CS = 1, bool TAB = false>
 __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
     // rows of U / U^-1: MTF full 16-row tiles on v_mfma_f64_16x16x4_f64 plus, for N = 20, the four
     // left-over rows on v_mfma_f64_4x4x4_4b_f64 (4 blocks = the tile's 4 groups of 4 patterns).
@@ -278,9 +349,11 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
             sUi4[t] = A.inv_evec[row * N + k];
         }
     }
-    if (TIP_COPY)
-        for (int t = threadIdx.x; t < N * N; t += WG) sUiT[t] = A.tip[t];  // tip[state][i] = U^-1[i][state]
-    for (int t = threadIdx.x; t < nx * N; t += WG) sTipx[t] = A.tip[N * N + t];
+    if (!TAB) {
+        if (TIP_COPY)
+            for (int t = threadIdx.x; t < N * N; t += WG) sUiT[t] = A.tip[t];  // tip[state][i] = U^-1[i][state]
+        for (int t = threadIdx.x; t < nx * N; t += WG) sTipx[t] = A.tip[N * N + t];
+    }
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -297,6 +370,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
     const double freq = A.freq[ptn];
     const double invar = A.invar[ptn];
     const CONST_AS DevOp *ops = as_const(A.ops);
+    const int S = A.state_unknown;                // rows of a leaf table
 
     v4f64 prev[C][MTF];
     double prevT[C];  // tail rows 16*MTF+g
@@ -309,12 +383,14 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
     int prev_sc = 0;
     double PFn[KS];
     int pfn_sc = 0;
+    int sLn = 0, sRn = 0;  // TAB: leaf states of the next op, requested one op ahead
     {   // prime: streamed child of (first op, category 0); the op after the last one is a sentinel
         const CONST_AS DevOp &f = ops[k_begin];
         const double *src = f.pf + ((f.real_mask & 1) ? tbase + (size_t)coff * N * 16 : 0);
 #pragma unroll
         for (int s = 0; s < KS; s++) PFn[s] = src[s * 64 + lane];
         if (g == 0) pfn_sc = f.pf_sc[(f.real_mask & 1) ? ptn : (int64_t)p];
+        if (TAB) { sLn = f.sl[ptn]; sRn = f.sr[ptn]; }
     }
 
     int k = k_begin;
@@ -324,6 +400,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
         for (int t = threadIdx.x; t < kn * 2 * B; t += WG) {
             const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B;
             const CONST_AS DevOp &d = ops[k + o];
+            if (TAB && (child ? d.right_kind : d.left_kind) == CHILD_LEAF) continue;  // a table child needs no exponentials
             const double len = child ? d.right_len : d.left_len;
             sReg[(child ? d.lds_right : d.lds_left) + e] = exp(A.eval[e % N] * (A.rates[e / N] * len));
         }
@@ -336,8 +413,15 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
             const bool leafL = op.left_kind == CHILD_LEAF, leafR = op.right_kind == CHILD_LEAF;
             const double *exL = sReg + op.lds_left, *exR = sReg + op.lds_right;
             int sc = 0, sL = 0, sR = 0;
-            if (leafL) sL = op.sl[ptn]; else sc += pfn_sc;          // pfn_sc: valid on g == 0 lanes
-            if (leafR) sR = op.sr[ptn];
+            if (TAB) {
+                sL = sLn; sR = sRn;
+                sLn = nxop.sl[ptn];   // (dummy rows for non-leaf children and the sentinel)
+                sRn = nxop.sr[ptn];
+                if (!leafL) sc += pfn_sc;
+            } else {
+                if (leafL) sL = op.sl[ptn]; else sc += pfn_sc;          // pfn_sc: valid on g == 0 lanes
+                if (leafR) sR = op.sr[ptn];
+            }
             if (op.right_kind == CHILD_LOAD) {
                 // rare (PF, LOAD): read the right child now into the `prev` registers
                 const double *src = op.ld + tbase;
@@ -359,6 +443,9 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
                 if (TIP_COPY) return sUiT[st * N + i];
                 return sUi[aidx<KS>(i >> 4, st >> 2, (st & 3) * 16 + (i & 15))];  // U^-1[i][st] in the A image
             };
+            // TAB: this lane's slice of the leaf children's table rows (4 contiguous doubles per M-tile)
+            const double *rowL = op.tabL + (size_t)(sL < S ? sL : 0) * N + 4 * g;
+            const double *rowR = op.tabR + (size_t)(sR < S ? sR : 0) * N + 4 * g;
             double *dst = op.dst + tbase;
             double lmax = 0.0;
 #pragma unroll
@@ -372,76 +459,117 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
                 // front; N = 64 (16 k-steps): stream it, the copies would not fit the register file.
                 // Measured on one box: protein 1.51 ms (copy) vs 1.63 ms (stream); codon 0.708 vs 0.678.
                 constexpr bool STREAM = (N >= 64);
-                double bl[STREAM ? 1 : KS], br[STREAM ? 1 : KS];
-                if constexpr (!STREAM) {
+                // one child product chain per non-table child (DOL / DOR compile-time): Y += U * (ex .* child)
+                auto chain = [&](auto DOL, auto DOR, v4f64 (&YL)[MTF], v4f64 (&YR)[MTF], double &yl4, double &yr4) {
+                    constexpr bool doL = decltype(DOL)::value, doR = decltype(DOR)::value;
+                    double bl[STREAM ? 1 : KS], br[STREAM ? 1 : KS];
+                    if constexpr (!STREAM) {
 #pragma unroll
-                    for (int s = 0; s < KS; s++) bl[s] = PFn[s];
+                        for (int s = 0; s < KS; s++) bl[s] = PFn[s];
 #pragma unroll
-                    for (int s = 0; s < KS; s++) PFn[s] = nsrc[s * 64 + lane];
-                    if (leafL) {
+                        for (int s = 0; s < KS; s++) PFn[s] = nsrc[s * 64 + lane];
+                        if (!TAB && leafL) {
 #pragma unroll
-                        for (int s = 0; s < KS; s++) bl[s] = tip_at(sL, 4 * s + g);
+                            for (int s = 0; s < KS; s++) bl[s] = tip_at(sL, 4 * s + g);
+                        }
+                        if (!TAB && leafR) {
+#pragma unroll
+                            for (int s = 0; s < KS; s++) br[s] = tip_at(sR, 4 * s + g);
+                        } else {
+#pragma unroll
+                            for (int s = 0; s < KS; s++) br[s] = (s < 4 * MTF) ? prev[c][(s >> 2) < MTF ? (s >> 2) : 0][s & 3] : prevT[c];
+                        }
                     }
-                    if (leafR) {
 #pragma unroll
-                        for (int s = 0; s < KS; s++) br[s] = tip_at(sR, 4 * s + g);
+                    for (int s = 0; s < KS; s++) {
+                        const int i = 4 * s + g;
+                        double vl = 0.0, vr = 0.0;
+                        if constexpr (STREAM) {
+                            if (doL) vl = (!TAB && leafL) ? tip_at(sL, i) : PFn[s];
+                            PFn[s] = nsrc[s * 64 + lane];
+                            if (doR) vr = (!TAB && leafR) ? tip_at(sR, i)
+                                                          : ((s < 4 * MTF) ? prev[c][(s >> 2) < MTF ? (s >> 2) : 0][s & 3] : prevT[c]);
+                        } else {
+                            vl = bl[s];
+                            vr = br[s];
+                        }
+                        if constexpr (doL) {
+                            const double xl = vl * exL[(coff + c) * N + i];
+#pragma unroll
+                            for (int m = 0; m < MTF; m++)
+                                YL[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(sU[aidx<KS>(m, s, lane)], xl, YL[m], 0, 0, 0);
+                            if (TAIL4) yl4 = __builtin_amdgcn_mfma_f64_4x4x4f64(sU4[s * 64 + lane], xl, yl4, 0, 0, 0);
+                        }
+                        if constexpr (doR) {
+                            const double xr = vr * exR[(coff + c) * N + i];
+#pragma unroll
+                            for (int m = 0; m < MTF; m++)
+                                YR[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(sU[aidx<KS>(m, s, lane)], xr, YR[m], 0, 0, 0);
+                            if (TAIL4) yr4 = __builtin_amdgcn_mfma_f64_4x4x4f64(sU4[s * 64 + lane], xr, yr4, 0, 0, 0);
+                        }
+                        // 64 states: keep the k-steps in program order, or the scheduler hoists all 16 operand
+                        // fetches above the first MFMA and the kernel spills
+                        if constexpr (STREAM) __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                using T_ = std::true_type;
+                using F_ = std::false_type;
+                // T = (U ex_L left) .* (U ex_R right); an unknown state (gap) at a leaf child counts as exactly 1.0
+                v4f64 T[MTF];
+                double t4 = 0.0;
+                auto hadamard = [&](v4f64 (&Y)[MTF], double y4, bool unkT, bool unkY) {  // T .*= Y with the selects
+                    if (anyUnk) {
+#pragma unroll
+                        for (int m = 0; m < MTF; m++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) T[m][r] = (unkT ? 1.0 : T[m][r]) * (unkY ? 1.0 : Y[m][r]);
+                        t4 = (unkT ? 1.0 : t4) * (unkY ? 1.0 : y4);
                     } else {
 #pragma unroll
-                        for (int s = 0; s < KS; s++) br[s] = (s < 4 * MTF) ? prev[c][(s >> 2) < MTF ? (s >> 2) : 0][s & 3] : prevT[c];
+                        for (int m = 0; m < MTF; m++) T[m] = T[m] * Y[m];
+                        t4 = t4 * y4;
                     }
-                }
-                v4f64 YL[MTF], YR[MTF];
-                double yl4 = 0.0, yr4 = 0.0;
+                };
+                // TAB: a leaf child's product is its pattern's row of the (L2-resident) table: requested before the
+                // other child's MFMA chain, multiplied in after it
+                auto table_row = [&](const double *row, v4f64 (&Y)[MTF], double &y4) {
+                    const double *r = row + (size_t)(coff + c) * S * N;
 #pragma unroll
-                for (int m = 0; m < MTF; m++) { YL[m] = (v4f64){0, 0, 0, 0}; YR[m] = (v4f64){0, 0, 0, 0}; }
+                    for (int m = 0; m < MTF; m++) Y[m] = *reinterpret_cast<const v4f64 *>(r + 16 * m);
+                    if (TAIL4) y4 = r[16 * MTF - 3 * g];   // (row carries +4g: tail row 16*MTF + g)
+                };
+                if (!TAB || (!leafL && !leafR)) {
+                    v4f64 YR[MTF];
+                    double yr4 = 0.0;
 #pragma unroll
-                for (int s = 0; s < KS; s++) {
-                    const int i = 4 * s + g;
-                    double vl, vr;
-                    if constexpr (STREAM) {
-                        vl = leafL ? tip_at(sL, i) : PFn[s];
-                        PFn[s] = nsrc[s * 64 + lane];
-                        vr = leafR ? tip_at(sR, i)
-                                   : ((s < 4 * MTF) ? prev[c][(s >> 2) < MTF ? (s >> 2) : 0][s & 3] : prevT[c]);
-                    } else {
-                        vl = bl[s];
-                        vr = br[s];
-                    }
-                    const double xl = vl * exL[(coff + c) * N + i];
-                    const double xr = vr * exR[(coff + c) * N + i];
+                    for (int m = 0; m < MTF; m++) { T[m] = (v4f64){0, 0, 0, 0}; YR[m] = (v4f64){0, 0, 0, 0}; }
+                    chain(T_{}, T_{}, T, YR, t4, yr4);
+                    hadamard(YR, yr4, unkL, unkR);
+                } else if (leafL && leafR) {
+                    v4f64 YR[MTF];
+                    double yr4 = 0.0;
+                    table_row(rowL, T, t4);
+                    table_row(rowR, YR, yr4);
+                    chain(F_{}, F_{}, T, YR, t4, yr4);   // (only refills the prefetch registers)
+                    hadamard(YR, yr4, unkL, unkR);
+                } else if (leafL) {
+                    v4f64 YR[MTF];
+                    double yr4 = 0.0;
+                    table_row(rowL, T, t4);
 #pragma unroll
-                    for (int m = 0; m < MTF; m++) {
-                        const double a = sU[aidx<KS>(m, s, lane)];
-                        YL[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xl, YL[m], 0, 0, 0);
-                        YR[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xr, YR[m], 0, 0, 0);
-                    }
-                    if (TAIL4) {
-                        const double a4 = sU4[s * 64 + lane];
-                        yl4 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4, xl, yl4, 0, 0, 0);
-                        yr4 = __builtin_amdgcn_mfma_f64_4x4x4f64(a4, xr, yr4, 0, 0, 0);
-                    }
-                    // 64 states: keep the k-steps in program order, or the scheduler hoists all 16 operand
-                    // fetches above the first MFMA and the kernel spills
-                    if constexpr (STREAM) __builtin_amdgcn_sched_barrier(0);
+                    for (int m = 0; m < MTF; m++) YR[m] = (v4f64){0, 0, 0, 0};
+                    chain(F_{}, T_{}, YR, YR, yr4, yr4);
+                    hadamard(YR, yr4, unkL, false);
+                } else {
+                    v4f64 YL[MTF];
+                    double yl4 = 0.0;
+                    table_row(rowR, T, t4);
+#pragma unroll
+                    for (int m = 0; m < MTF; m++) YL[m] = (v4f64){0, 0, 0, 0};
+                    chain(T_{}, F_{}, YL, YL, yl4, yl4);
+                    hadamard(YL, yl4, unkR, false);
                 }
                 if (c + 1 == C && g == 0) pfn_sc = nd.pf_sc[nreal ? ptn : (int64_t)p];
-                v4f64 T[MTF];
-                double t4;
-                if (anyUnk) {  // wave-uniform: some lane holds an unknown state (gap) at a leaf child
-#pragma unroll
-                    for (int m = 0; m < MTF; m++)
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const double a = unkL ? 1.0 : YL[m][r];
-                            const double b = unkR ? 1.0 : YR[m][r];
-                            T[m][r] = a * b;
-                        }
-                    t4 = (unkL ? 1.0 : yl4) * (unkR ? 1.0 : yr4);
-                } else {
-#pragma unroll
-                    for (int m = 0; m < MTF; m++) T[m] = YL[m] * YR[m];
-                    t4 = yl4 * yr4;
-                }
                 v4f64 O[MTF];
                 double o4 = 0.0;
 #pragma unroll
@@ -715,7 +843,7 @@ static hipError_t launch_trav_mix20(iqhip_engine *e, TravMArgs &A) {
 // LDS as B-operand k-step slices (the accumulator image of M-tile w IS k-steps 4w..4w+3), one workgroup barrier
 // each; the scaling maximum takes a third.  Same canonical plan form as k_traverse_mfma2 (C = 1).
 // ---------------------------------------------------------------------------------------
-template <int WG>
+template <int WG, bool TAB>
 __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_rows64(const TravMArgs A) {
     constexpr int N = 64, KS = 16, B = 64;
     static_assert(WG == 256, "one tile per workgroup of four waves");
@@ -808,15 +936,25 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_rows64(const TravMArgs 
             const bool nreal = nxop.real_mask & 1;
             const double *nsrc = nxop.pf + (nreal ? tbase : 0);
             v4f64 YL = {0, 0, 0, 0}, YR = {0, 0, 0, 0};
+            const bool tabL = TAB && leafL, tabR = TAB && leafR;
+            if (TAB) {  // leaf children: this wave's 16 rows of the pattern's table row (k_leaf_tables)
+                const int S = A.state_unknown;
+                if (leafL) YL = *reinterpret_cast<const v4f64 *>(op.tabL + (size_t)(sL < S ? sL : 0) * N + 16 * wave + 4 * g);
+                if (leafR) YR = *reinterpret_cast<const v4f64 *>(op.tabR + (size_t)(sR < S ? sR : 0) * N + 16 * wave + 4 * g);
+            }
 #pragma unroll
             for (int s = 0; s < KS; s++) {
                 const int i = 4 * s + g;
                 const double vl = leafL ? sTip[sL * N + i] : PFn[s];
                 PFn[s] = nsrc[s * 64 + lane];
-                const double xl = vl * exL[i];
-                const double xrs = xr[s] * exR[i];
-                YL = __builtin_amdgcn_mfma_f64_16x16x4f64(aU[s], xl, YL, 0, 0, 0);
-                YR = __builtin_amdgcn_mfma_f64_16x16x4f64(aU[s], xrs, YR, 0, 0, 0);
+                if (!tabL) {
+                    const double xl = vl * exL[i];
+                    YL = __builtin_amdgcn_mfma_f64_16x16x4f64(aU[s], xl, YL, 0, 0, 0);
+                }
+                if (!tabR) {
+                    const double xrs = xr[s] * exR[i];
+                    YR = __builtin_amdgcn_mfma_f64_16x16x4f64(aU[s], xrs, YR, 0, 0, 0);
+                }
             }
             if (g == 0) pfn_sc = nxop.pf_sc[nreal ? ptn : (int64_t)p];
             double *tb = sT + par * KS * 64;
@@ -861,19 +999,20 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_rows64(const TravMArgs 
     }
 }
 
+template <bool TAB>
 static hipError_t launch_trav_rows64(iqhip_engine *e, TravMArgs &A) {
     constexpr int WG = 256;
     const int nx = e->state_unknown + 1 - 64;
     const size_t lds = (size_t)((64 + nx) * 64 + 4 * 16 * 64 + e->plan_lds_doubles) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma_rows64<WG>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma_rows64<WG, TAB>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
     A.ngroups = (int)A.ntiles;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((k_traverse_mfma_rows64<WG>), dim3((unsigned)(A.ngroups * A.nsegs_launch)), dim3(WG), lds, e->stream, A);
+    hipLaunchKernelGGL((k_traverse_mfma_rows64<WG, TAB>), dim3((unsigned)(A.ngroups * A.nsegs_launch)), dim3(WG), lds, e->stream, A);
     return hipGetLastError();
 }
 
@@ -883,21 +1022,21 @@ int mfma2_fixed_lds_doubles(int n) {
     return 2 * mtf * ks * 64 + ((n % 16) == 4 ? 2 * ks * 64 : 0) + (n * n * 8 <= 4096 ? n * n : 0);
 }
 
-template <int N, int C, int CS = 1>
+template <int N, int C, int CS = 1, bool TAB = false>
 static hipError_t launch_trav_m2(iqhip_engine *e, TravMArgs &A) {
     constexpr int KS = N / 4, WG = 256;
     const int nx = e->state_unknown + 1 - N;
     const size_t lds = (size_t)(mfma2_fixed_lds_doubles(N) + nx * N + e->plan_lds_doubles) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma2<N, C, WG, CS>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma2<N, C, WG, CS, TAB>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
     A.ngroups = (int)((A.ntiles * CS + 3) / 4);
     const int grid = A.ngroups * A.nsegs_launch;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((k_traverse_mfma2<N, C, WG, CS>), dim3(grid), dim3(WG), lds, e->stream, A);
+    hipLaunchKernelGGL((k_traverse_mfma2<N, C, WG, CS, TAB>), dim3(grid), dim3(WG), lds, e->stream, A);
     return hipGetLastError();
 }
 
@@ -926,9 +1065,16 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs
     A.state_unknown = e->state_unknown;
     if (nsegs <= 0) return hipSuccess;
     if (e->mfma_pipelined) {  // plan was built in canonical (PF, PREV) form
+        if (e->plan_nleaf_tabs > 0 || e->leaf_tables) {  // leaf children from the K2 tables (k_leaf_tables)
+            if (e->n == 20 && e->ncat == 4)
+                return e->cat_split ? launch_trav_m2<20, 1, 4, true>(e, A) : launch_trav_m2<20, 4, 1, true>(e, A);
+            if (e->n == 20 && e->ncat == 1) return launch_trav_m2<20, 1, 1, true>(e, A);
+            if (e->n == 64 && e->ncat == 1) return e->row_split ? launch_trav_rows64<true>(e, A) : launch_trav_m2<64, 1, 1, true>(e, A);
+            return hipErrorInvalidValue;
+        }
         if (e->n == 20 && e->ncat == 4) return e->cat_split ? launch_trav_m2<20, 1, 4>(e, A) : launch_trav_m2<20, 4>(e, A);
         if (e->n == 20 && e->ncat == 1) return launch_trav_m2<20, 1>(e, A);
-        if (e->n == 64 && e->ncat == 1) return e->row_split ? launch_trav_rows64(e, A) : launch_trav_m2<64, 1>(e, A);
+        if (e->n == 64 && e->ncat == 1) return e->row_split ? launch_trav_rows64<false>(e, A) : launch_trav_m2<64, 1>(e, A);
         return hipErrorInvalidValue;
     }
     switch (e->n) {

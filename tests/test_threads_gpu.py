@@ -61,7 +61,7 @@ def test_multi_workgroup_newton_solves_of_two_engines_overlap(pkg, synth, oracle
     single-threaded ones."""
     trees = []
     for k in range(2):
-        t, ot, *_ = make_case(synth, oracle, pkg, 10, 110000, 4, 4, 9950 + k, mem_mode=pkg.LM_ALL_BRANCH)
+        t, ot, *_ = make_case(synth, oracle, pkg, 40, 150000, 4, 4, 9950 + k, mem_mode=pkg.LM_ALL_BRANCH)
         assert t.nptn >= 100000
         t.compute_likelihood()
         trees.append(t)
