@@ -472,6 +472,7 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
     e->state_unknown = state_unknown;
     e->model_set = true;
     e->theta_valid = false;
+    e->model_version++;
     return IQHIP_OK;
 }
 
@@ -575,7 +576,10 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
     // their own workgroups in a first launch (tiles x units waves), and only the ops above them
     // ("top") walk sequentially in a second launch.  order[p] = caller index of the op at position p.
     std::vector<int> order(nops), seg_of(nops, 0);
-    std::vector<std::pair<int, int>> units;  // {begin, nops} in the new order
+    std::vector<std::pair<int, int>> units;  // {begin, nops} in the new order, stage after stage
+    std::vector<int> stage_units;            // units per stage (launch)
+    int max_levels = 3;
+    if (const char *ml = getenv("IQHIP_LEVELS")) max_levels = std::max(1, atoi(ml));
     int top_begin = 0;
     for (int k = 0; k < nops; k++) order[k] = k;
     if (explicit_segs) {
@@ -593,6 +597,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
             pos += n;
         }
         if (pos != nops) return fail(IQHIP_ERR_INVALID, "segment sizes do not add up to the op count");
+        stage_units.push_back((int)units.size());
         top_begin = nops;
     } else {
         int target = e->split_target;
@@ -613,8 +618,8 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         if (target > 0 && target < nops && nops >= 4) {
             std::unordered_map<uint64_t, int> prod;
             std::unordered_set<uint64_t> ext_in;
-            std::vector<int> lc(nops, -1), rc(nops, -1), sz(nops, 1);
-            std::vector<char> consumed(nops, 0), contiguous(nops, 1);
+            std::vector<int> lc(nops, -1), rc(nops, -1);
+            std::vector<char> consumed(nops, 0);
             bool safe = true;
             for (int k = 0; k < nops && safe; k++) {
                 const iqhip_node_op &o = ops[k];
@@ -626,14 +631,8 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
                 };
                 lc[k] = child(o.left_key, o.left_leaf);
                 rc[k] = child(o.right_key, o.right_leaf);
-                if (lc[k] >= 0) { if (consumed[lc[k]]) safe = false; consumed[lc[k]] = 1; sz[k] += sz[lc[k]]; }
-                if (rc[k] >= 0) { if (consumed[rc[k]]) safe = false; consumed[rc[k]] = 1; sz[k] += sz[rc[k]]; }
-                // post-order contiguity: the subtree of k is exactly [k - sz + 1, k]
-                const int a = std::max(lc[k], rc[k]), b2 = std::min(lc[k], rc[k]);
-                bool cont = true;
-                if (a >= 0) cont = (a == k - 1) && contiguous[a];
-                if (b2 >= 0) cont = cont && (b2 == a - sz[a]) && contiguous[b2];
-                contiguous[k] = cont;
+                if (lc[k] >= 0) { if (consumed[lc[k]]) safe = false; consumed[lc[k]] = 1; }
+                if (rc[k] >= 0) { if (consumed[rc[k]]) safe = false; consumed[rc[k]] = 1; }
                 // re-ordering is only safe when no vector of the plan is both an outside input and a
                 // destination (LM_PER_NODE buffer stealing) and nothing is written twice
                 if (prod.count(o.dst_key)) safe = false;
@@ -642,48 +641,89 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
             for (int k = 0; k < nops && safe; k++)
                 if (ext_in.count(ops[k].dst_key)) safe = false;
             if (safe) {
-                std::vector<char> in_unit(nops, 0);
-                std::vector<int> stack;
-                for (int k = nops - 1; k >= 0; k--)
-                    if (!consumed[k]) stack.push_back(k);
-                std::vector<std::pair<int, int>> found;  // {root, size}
-                while (!stack.empty()) {
-                    const int k = stack.back();
-                    stack.pop_back();
-                    if (sz[k] <= target && sz[k] >= 2 && contiguous[k]) {
-                        found.push_back({k, sz[k]});
-                        for (int q = k - sz[k] + 1; q <= k; q++) in_unit[q] = 1;
-                    } else {
-                        if (lc[k] >= 0) stack.push_back(lc[k]);
-                        if (rc[k] >= 0) stack.push_back(rc[k]);
+                // Level by level: among the ops not yet placed, the maximal subtrees of 2..target ops (vectors of
+                // earlier levels count as outside inputs) become the units of the next launch; what is left after
+                // the last level walks sequentially.  Every level is a launch of tiles x units waves, so the
+                // sequential tail -- where an alignment with slightly more tiles than SIMDs runs at half speed --
+                // shrinks from "everything above the first cut" to a few ops.
+                std::vector<char> placed(nops, 0);
+                std::vector<int> new_order;
+                new_order.reserve(nops);
+                int nseg = 0, left = nops;
+                const int min_top = std::max(2, std::min(target, 6));
+                for (int level = 0; level < max_levels && left > min_top; level++) {
+                    std::vector<int> rem;  // unplaced ops in post-order
+                    for (int k = 0; k < nops; k++)
+                        if (!placed[k]) rem.push_back(k);
+                    const int R = (int)rem.size();
+                    std::vector<int> pos_of(nops, -1), l2(R, -1), r2(R, -1), sz(R, 1);
+                    std::vector<char> cont(R, 1), cons(R, 0);
+                    for (int q = 0; q < R; q++) pos_of[rem[q]] = q;
+                    for (int q = 0; q < R; q++) {
+                        const int k = rem[q];
+                        if (lc[k] >= 0 && !placed[lc[k]]) { l2[q] = pos_of[lc[k]]; cons[l2[q]] = 1; sz[q] += sz[l2[q]]; }
+                        if (rc[k] >= 0 && !placed[rc[k]]) { r2[q] = pos_of[rc[k]]; cons[r2[q]] = 1; sz[q] += sz[r2[q]]; }
+                        // post-order contiguity within the unplaced sequence: the subtree of q is exactly [q - sz + 1, q]
+                        const int a = std::max(l2[q], r2[q]), b2 = std::min(l2[q], r2[q]);
+                        bool c2 = true;
+                        if (a >= 0) c2 = (a == q - 1) && cont[a];
+                        if (b2 >= 0) c2 = c2 && (b2 == a - sz[a]) && cont[b2];
+                        cont[q] = c2;
                     }
-                }
-                if (found.size() >= 2) {
-                    std::stable_sort(found.begin(), found.end(),
-                                     [](const std::pair<int, int> &x, const std::pair<int, int> &y2) { return x.second > y2.second; });
-                    int pos = 0;
-                    for (size_t u = 0; u < found.size(); u++) {
-                        units.push_back({pos, found[u].second});
-                        for (int q = found[u].first - found[u].second + 1; q <= found[u].first; q++) {
-                            seg_of[pos] = (int)u + 1;
-                            order[pos++] = q;
+                    std::vector<int> stack;
+                    for (int q = R - 1; q >= 0; q--)
+                        if (!cons[q]) stack.push_back(q);
+                    std::vector<std::pair<int, int>> found;  // {root position, size}
+                    while (!stack.empty()) {
+                        const int q = stack.back();
+                        stack.pop_back();
+                        if (sz[q] <= target && sz[q] >= 2 && cont[q]) {
+                            found.push_back({q, sz[q]});
+                        } else {
+                            if (l2[q] >= 0) stack.push_back(l2[q]);
+                            if (r2[q] >= 0) stack.push_back(r2[q]);
                         }
                     }
-                    top_begin = pos;
+                    if (found.size() < 2) break;
+                    std::stable_sort(found.begin(), found.end(),
+                                     [](const std::pair<int, int> &x, const std::pair<int, int> &y2) { return x.second > y2.second; });
+                    int in_stage = 0;
+                    for (size_t u = 0; u < found.size(); u++) {
+                        units.push_back({(int)new_order.size(), found[u].second});
+                        nseg++;
+                        in_stage++;
+                        for (int q = found[u].first - found[u].second + 1; q <= found[u].first; q++) {
+                            seg_of[new_order.size()] = nseg;
+                            placed[rem[q]] = 1;
+                            new_order.push_back(rem[q]);
+                            left--;
+                        }
+                    }
+                    stage_units.push_back(in_stage);
+                }
+                if (!units.empty()) {
+                    top_begin = (int)new_order.size();
                     for (int k = 0; k < nops; k++)
-                        if (!in_unit[k]) { seg_of[pos] = 0; order[pos++] = k; }
+                        if (!placed[k]) { seg_of[new_order.size()] = 0; new_order.push_back(k); }
+                    order = new_order;
                 }
             }
         }
     }
     if (getenv("IQHIP_DEBUG_PLAN")) {
-        fprintf(stderr, "[iqhip] plan: %d ops, %zu units (", nops, units.size());
-        for (auto &u : units) fprintf(stderr, "%d ", u.second);
+        fprintf(stderr, "[iqhip] plan: %d ops, %zu stages of units (", nops, stage_units.size());
+        size_t ui = 0;
+        for (int n : stage_units) {
+            for (int q = 0; q < n; q++) fprintf(stderr, "%d ", units[ui++].second);
+            fprintf(stderr, "| ");
+        }
         fprintf(stderr, ") top %d ops\n", nops - top_begin);
     }
     const int table_ints = 2 * (1 + (int)units.size());
     const int table_ops = (int)((table_ints * sizeof(int) + sizeof(DevOp) - 1) / sizeof(DevOp));
-    rc = ensure_plan_capacity(e, nops + kSentinels + table_ops);
+    // (room for the K2 table job list behind the segment table: at most two leaf children per op)
+    const int jobs_ops_max = (int)((sizeof(TabJob) * (size_t)(2 * nops + 1) + sizeof(DevOp) - 1) / sizeof(DevOp));
+    rc = ensure_plan_capacity(e, nops + kSentinels + table_ops + jobs_ops_max);
     if (rc) return rc;
     auto dummy_op = [&](DevOp &d) {
         memset(&d, 0, sizeof(d));
@@ -778,32 +818,78 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
             producer[d.dst] = k;
         }
     }
-    // K2 tables of the leaf children (pipelined matrix-core kernels): one slot per (op, leaf side), filled by
-    // k_leaf_tables before the traversal kernel of this submission
+    // K2 tables of the leaf children (pipelined matrix-core kernels): slot = taxon, rebuilt by k_leaf_tables before
+    // the traversal only where the pendant branch length (or the model) changed since the slot was last built
     e->plan_nleaf_tabs = 0;
+    e->plan_tab_jobs.clear();
+    e->plan_tab_dirty = 0;
     if (e->mfma && e->mfma_pipelined && e->leaf_tables) {
-        int ntab = 0;
-        for (int k = 0; k < nops; k++)
-            ntab += (e->h_ops[k].left_kind == CHILD_LEAF) + (e->h_ops[k].right_kind == CHILD_LEAF);
         const size_t per = leaf_table_doubles(e);
-        const size_t need = std::max<size_t>(1, (size_t)ntab) * per;
-        if (need > e->leaf_tab_cap) {
+        struct Use { double len; int slot; };
+        std::unordered_map<int, std::vector<Use>> seen;  // taxon -> lengths used in this plan
+        int noverflow = 0;
+        std::vector<TabJob> dirty, clean;
+        std::vector<std::pair<int, int>> uses;  // (op index, side) -> slot, resolved to pointers after (re)allocation
+        std::vector<int> use_slot;
+        const bool model_changed = e->tab_model_version != e->model_version;
+        for (int k = 0; k < nops; k++) {
+            DevOp &d = e->h_ops[k];
+            for (int side = 0; side < 2; side++) {
+                if ((side ? d.right_kind : d.left_kind) != CHILD_LEAF) continue;
+                const uint8_t *row = side ? d.sr : d.sl;
+                const int taxon = (int)((row - e->d_states) / e->nptn_pad);
+                const double len = side ? d.right_len : d.left_len;
+                std::vector<Use> &u = seen[taxon];
+                int slot = -1;
+                for (const Use &x : u)
+                    if (x.len == len) slot = x.slot;
+                if (slot < 0) {
+                    slot = u.empty() ? taxon : e->ntaxa + noverflow++;
+                    u.push_back({len, slot});
+                    TabJob j;
+                    j.len = len;
+                    j.tab = reinterpret_cast<double *>((size_t)slot);  // slot number for now
+                    const bool cached = slot < e->ntaxa && !model_changed && (size_t)slot < e->tab_len.size() &&
+                                        e->tab_len[slot] == len;
+                    (cached ? clean : dirty).push_back(j);
+                }
+                uses.push_back({k, side});
+                use_slot.push_back(slot);
+            }
+        }
+        const size_t need = (size_t)e->ntaxa + (size_t)noverflow;
+        if (need > e->leaf_tab_slots) {
             HIPCHK(hipStreamSynchronize(e->stream));
             if (e->d_leaf_tab) hipFree(e->d_leaf_tab);
             e->d_leaf_tab = nullptr;
-            e->leaf_tab_cap = 0;
-            HIPCHK(dmalloc(&e->d_leaf_tab, need * 2));
-            e->leaf_tab_cap = need * 2;
+            e->leaf_tab_slots = 0;
+            const size_t slots = need + 16;
+            HIPCHK(dmalloc(&e->d_leaf_tab, slots * per));
+            e->leaf_tab_slots = slots;
             e->uploaded_plan.clear();
+            // a new buffer holds no tables: everything this plan uses is dirty
+            dirty.insert(dirty.end(), clean.begin(), clean.end());
+            clean.clear();
+            e->tab_len.assign(slots, NAN);
         }
-        int slot = 0;
-        for (int k = 0; k < nops; k++) {
-            DevOp &d = e->h_ops[k];
-            d.tabL = d.tabR = e->d_leaf_tab;
-            if (d.left_kind == CHILD_LEAF) d.tabL = e->d_leaf_tab + (size_t)(slot++) * per;
-            if (d.right_kind == CHILD_LEAF) d.tabR = e->d_leaf_tab + (size_t)(slot++) * per;
+        if (e->tab_len.size() < e->leaf_tab_slots) e->tab_len.resize(e->leaf_tab_slots, NAN);
+        if (model_changed) {  // tables of other plans are stale as well
+            std::fill(e->tab_len.begin(), e->tab_len.end(), NAN);
+            e->tab_model_version = e->model_version;
         }
-        e->plan_nleaf_tabs = ntab;
+        for (size_t q = 0; q < uses.size(); q++) {
+            DevOp &d = e->h_ops[uses[q].first];
+            (uses[q].second ? d.tabR : d.tabL) = e->d_leaf_tab + (size_t)use_slot[q] * per;
+        }
+        for (std::vector<TabJob> *v : {&dirty, &clean})
+            for (TabJob &j : *v) {
+                const size_t slot = (size_t)j.tab;
+                j.tab = e->d_leaf_tab + slot * per;
+                e->tab_len[slot] = slot < (size_t)e->ntaxa ? j.len : NAN;  // overflow slots are never reused
+                e->plan_tab_jobs.push_back(j);
+            }
+        e->plan_tab_dirty = (int)dirty.size();
+        e->plan_nleaf_tabs = (int)e->plan_tab_jobs.size();
     }
     for (int q = 0; q < kSentinels; q++) dummy_op(e->h_ops[nops + q]);  // targets of the look-ahead requests
     *last_dst = prev_dst;
@@ -861,10 +947,17 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         tab[1] = nops - top_begin;
         for (size_t u = 0; u < units.size(); u++) { tab[2 + 2 * u] = units[u].first; tab[3 + 2 * u] = units[u].second; }
         e->plan_nunits = (int)units.size();
+        e->plan_stage_units = stage_units;
         e->plan_top_nops = nops - top_begin;
         e->plan_table_off = nops + kSentinels;
     }
-    const size_t nbytes = sizeof(DevOp) * (size_t)(nops + kSentinels + table_ops);
+    e->plan_jobs_off = nops + kSentinels + table_ops;
+    const int jobs_ops = (int)((sizeof(TabJob) * e->plan_tab_jobs.size() + sizeof(DevOp) - 1) / sizeof(DevOp));
+    if (jobs_ops > 0) {
+        memset(e->h_ops + e->plan_jobs_off, 0, sizeof(DevOp) * (size_t)jobs_ops);
+        memcpy(e->h_ops + e->plan_jobs_off, e->plan_tab_jobs.data(), sizeof(TabJob) * e->plan_tab_jobs.size());
+    }
+    const size_t nbytes = sizeof(DevOp) * (size_t)(nops + kSentinels + table_ops + jobs_ops);
     e->last_ops_in.assign((const char *)ops, (const char *)ops + in_bytes);
     e->last_segs = segs_in;
     e->last_plan_version = e->keymap_version;  // (slabs created while building are included)
@@ -927,19 +1020,39 @@ static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, 
     rc = ensure_slab_rows(e, 2 + nops);
     if (rc) return rc;
     const int nwaves = (int)e->ntiles * e->lane_split;  // columns of the wave-partial slab
-    if (e->plan_nleaf_tabs > 0) HIPCHK(launch_leaf_tables(e, nops));
+    if (e->plan_nleaf_tabs > 0) {
+        // tables whose branch length changed since they were built -- all of the plan's after a model change
+        // (a cached plan skipped build_plan, which is where a model change is normally noticed)
+        int njobs = e->plan_tab_dirty;
+        if (e->tab_model_version != e->model_version) {
+            std::fill(e->tab_len.begin(), e->tab_len.end(), NAN);
+            for (const TabJob &j : e->plan_tab_jobs) {
+                const size_t slot = (size_t)(j.tab - e->d_leaf_tab) / leaf_table_doubles(e);
+                if (slot < (size_t)e->ntaxa) e->tab_len[slot] = j.len;
+            }
+            e->tab_model_version = e->model_version;
+            njobs = e->plan_nleaf_tabs;
+        }
+        if (njobs > 0)
+            HIPCHK(launch_leaf_tables(e, reinterpret_cast<const TabJob *>(e->d_ops + e->plan_jobs_off), njobs));
+        e->plan_tab_dirty = 0;  // built; the same (cached) plan needs nothing until a length or the model changes
+    }
     timing_begin(e);
     const int *table = reinterpret_cast<const int *>(e->d_ops + e->plan_table_off);
-    if (e->plan_nunits > 0) {  // stage 1: the independent subtrees, one set of workgroups each
-        if (e->mfma) HIPCHK(launch_traverse_mfma(e, table + 2, e->plan_nunits, nwaves));
-        else HIPCHK(launch_traverse4(e, table + 2, e->plan_nunits, e->plan_units_have_load, nullptr, nwaves));
+    {   // the stages of independent subtrees, level by level: one launch each, one set of workgroups per unit
+        int off = 2;
+        for (int n : e->plan_stage_units) {
+            if (e->mfma) HIPCHK(launch_traverse_mfma(e, table + off, n, nwaves));
+            else HIPCHK(launch_traverse4(e, table + off, n, e->plan_units_have_load, nullptr, nwaves));
+            off += 2 * n;
+        }
     }
     const bool empty_top = e->plan_nunits > 0 && !has_root && e->plan_top_nops == 0;  // explicit segments only
     if (empty_top) {
     } else if (e->mfma) HIPCHK(launch_traverse_mfma(e, table, nops > 0 ? 1 : 0, nwaves));
     else HIPCHK(launch_traverse4(e, table, 1, e->plan_has_load, has_root ? &br : nullptr, nwaves));
     timing_end(e);
-    if (e->timing) e->tev_launches += (e->plan_nunits > 0) ? 2 : 1;
+    if (e->timing) e->tev_launches += (int)e->plan_stage_units.size() + (empty_top ? 0 : 1);
     if (e->mfma && has_root) HIPCHK(launch_stream_mfma(e, 0, &br, br.len, nwaves));
     if (has_root) HIPCHK(launch_reduce(e, 0, 2 + nops, nwaves));
     else if (!skip_reduce) HIPCHK(launch_reduce(e, 2, nops, nwaves));

@@ -76,6 +76,11 @@ struct Slab {
     int16_t *sc = nullptr;
 };
 
+struct __attribute__((aligned(16))) TabJob {  // one K2 table to build: tab[c][state][pos(x)] for branch length len
+    double len;
+    double *tab;
+};
+
 // Optimization::minimizeNewton (optimization.cpp:388-465) as a state machine that is advanced once per derivative
 // evaluation: `newton_init`, then after every evaluation at `rts` one `newton_update(sum f*df_ptn, sum f*ddf_ptn)`
 // until `done`.  The same function runs in a 1-thread kernel (sharded engines: derivative kernel -> all-reduce of
@@ -162,6 +167,7 @@ struct iqhip_engine {
     // first launch, the ops above them ("top") in a second one.  Segment table on the device, after the
     // sentinel descriptors: {top_begin, top_nops, unit1_begin, unit1_nops, ...}
     int plan_nunits = 0;
+    std::vector<int> plan_stage_units;  // units per stage, in launch order
     int plan_top_nops = 0;
     std::vector<int> last_segs;   // explicit segment sizes the cached descriptors were built with
     int plan_table_off = 0;      // DevOp index where the table starts
@@ -195,9 +201,18 @@ struct iqhip_engine {
     double *d_slab = nullptr;   // wave partials [nvals][nwaves]
     int64_t slab_cap = 0;
     double *d_theta = nullptr, *d_pattern_lh = nullptr;
-    double *d_leaf_tab = nullptr;   // K2 tables of the current plan's leaf children (matrix-core pipelined kernels)
-    size_t leaf_tab_cap = 0;        // doubles
-    int plan_nleaf_tabs = 0;        // tables the current plan needs (0: kernel variant without tables)
+    // K2 tables of the leaf children (matrix-core pipelined kernels, kernels_mfma.hip k_leaf_tables).  A table depends
+    // on (model, pendant branch length) only, so slot t < ntaxa belongs to taxon t and is rebuilt only when that
+    // length or the model changed; a second length of one taxon inside one submission (batched NNI candidates)
+    // takes an overflow slot >= ntaxa.
+    double *d_leaf_tab = nullptr;
+    size_t leaf_tab_slots = 0;            // capacity in tables
+    std::vector<double> tab_len;          // per slot: branch length the table was built for (NaN: none)
+    uint64_t model_version = 1, tab_model_version = 0;
+    std::vector<iqhip::TabJob> plan_tab_jobs;  // the current plan's tables: [0, plan_tab_dirty) need (re)building
+    int plan_tab_dirty = 0;
+    int plan_jobs_off = 0;                // DevOp index where the device copy of the job list starts
+    int plan_nleaf_tabs = 0;              // tables the current plan uses (0: kernel variant without tables)
     bool leaf_tables = false;       // IQHIP_LEAF_TABLES (default on for the pipelined matrix-core kernels)
     // Mixture models (phylokernelmixture.h, phylokernelmixrate.h): the ncat categories are (class, rate)
     // components; category c uses eigen-system cat_class[c].  Per-category expansions for the kernels
@@ -355,7 +370,7 @@ void newton_task_fill(void *dst, const DevBranch &br, double xguess, double x1, 
 
 // kernels_mfma.hip (nstates 20 / 64)
 hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs, int nwaves);
-hipError_t launch_leaf_tables(iqhip_engine *e, int nops);  // K2 tables of every leaf child of d_ops[0..nops)
+hipError_t launch_leaf_tables(iqhip_engine *e, const TabJob *d_jobs, int njobs);
 size_t leaf_table_doubles(const iqhip_engine *e);          // doubles per (leaf child) table: ncat * state_unknown * n
 int mfma2_fixed_lds_doubles(int n);
 // mode 0: branch lnL, 1: theta, 2: df/ddf from theta, 3: lnL from theta

@@ -244,51 +244,60 @@ __host__ __device__ inline int leaf_tab_pos(int x, int n) {
     return (x & ~15) + 4 * (w & 3) + (w >> 2);
 }
 
-__global__ __launch_bounds__(256) void k_leaf_tables(const DevOp *ops, int n, int ncat, int nstate_rows,
+// block = (job, category, state range): thread <-> row x of U (its E row lives in registers), the block's thread groups
+// share out the states of the range; tip vectors are LDS broadcasts
+template <int N>
+__global__ __launch_bounds__(256) void k_leaf_tables(const TabJob *jobs, int ncat, int nstate_rows, int nsplit,
                                                      const double *__restrict__ eval, const double *__restrict__ evec,
                                                      const double *__restrict__ rates, const double *__restrict__ tip) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int k = blockIdx.x / (2 * ncat), r = blockIdx.x - k * 2 * ncat, side = r / ncat, c = r - side * ncat;
-    const DevOp &d = ops[k];
-    if ((side ? d.right_kind : d.left_kind) != CHILD_LEAF) return;
-    const double len = side ? d.right_len : d.left_len;
-    double *tab = const_cast<double *>(side ? d.tabR : d.tabL) + (size_t)c * nstate_rows * n;
-    const int ld = n + 1;                 // padded rows: lanes walk different x
-    double *sE = smem;                    // [n][n+1]  E[x][i] = U[x][i] * exp(eval_i r_c t), rounded (K1, :159-181)
-    double *sTip = smem + n * ld;         // [nstate_rows][n]
-    for (int t = threadIdx.x; t < n * n; t += 256) {
-        const int x = t / n, i = t - x * n;
-        sE[x * ld + i] = __dmul_rn(evec[x * n + i], exp(eval[i] * (rates[c] * len)));
-    }
-    for (int t = threadIdx.x; t < nstate_rows * n; t += 256) sTip[t] = tip[t];
+    constexpr int GW = (N > 32) ? 64 : 32;   // threads per group (one thread per x, padded)
+    constexpr int NG = 256 / GW;             // groups per block
+    __shared__ double s_ex[N];
+    extern __shared__ __attribute__((aligned(16))) double s_tip[];  // [rows of this block][N]
+    const int job = blockIdx.x / (ncat * nsplit), r = blockIdx.x - job * ncat * nsplit, c = r / nsplit, sp = r - c * nsplit;
+    const double len = jobs[job].len;
+    double *tab = jobs[job].tab + (size_t)c * nstate_rows * N;
+    const int per = (nstate_rows + nsplit - 1) / nsplit, s_lo = sp * per, s_hi = min(nstate_rows, s_lo + per);
+    if (threadIdx.x < N) s_ex[threadIdx.x] = exp(eval[threadIdx.x] * (rates[c] * len));
+    for (int t = threadIdx.x; t < (s_hi - s_lo) * N; t += 256) s_tip[t] = tip[(size_t)s_lo * N + t];
     __syncthreads();
-    for (int t = threadIdx.x; t < nstate_rows * n; t += 256) {
-        const int s = t / n, x = t - s * n;
-        const double *a = sE + x * ld, *b = sTip + s * n;
-        double l0 = __dmul_rn(a[0], b[0]), l1 = __dmul_rn(a[1], b[1]), l2 = __dmul_rn(a[2], b[2]), l3 = __dmul_rn(a[3], b[3]);
-        for (int i = 4; i < n; i += 4) {
-            l0 = __dadd_rn(__dmul_rn(a[i], b[i]), l0);
-            l1 = __dadd_rn(__dmul_rn(a[i + 1], b[i + 1]), l1);
-            l2 = __dadd_rn(__dmul_rn(a[i + 2], b[i + 2]), l2);
-            l3 = __dadd_rn(__dmul_rn(a[i + 3], b[i + 3]), l3);
+    const int x = threadIdx.x % GW, grp = threadIdx.x / GW;
+    if (x >= N) return;
+    double E[N];  // E[x][i] = U[x][i] * exp(eval_i r_c t), rounded (K1, phylokernel.h:159-181)
+#pragma unroll
+    for (int i = 0; i < N; i++) E[i] = __dmul_rn(evec[x * N + i], s_ex[i]);
+    const int pos = leaf_tab_pos(x, N);
+    for (int s = s_lo + grp; s < s_hi; s += NG) {
+        const double *b = s_tip + (size_t)(s - s_lo) * N;
+        double l0 = __dmul_rn(E[0], b[0]), l1 = __dmul_rn(E[1], b[1]), l2 = __dmul_rn(E[2], b[2]), l3 = __dmul_rn(E[3], b[3]);
+#pragma unroll
+        for (int i = 4; i < N; i += 4) {
+            l0 = __dadd_rn(__dmul_rn(E[i], b[i]), l0);
+            l1 = __dadd_rn(__dmul_rn(E[i + 1], b[i + 1]), l1);
+            l2 = __dadd_rn(__dmul_rn(E[i + 2], b[i + 2]), l2);
+            l3 = __dadd_rn(__dmul_rn(E[i + 3], b[i + 3]), l3);
         }
-        tab[(size_t)s * n + leaf_tab_pos(x, n)] = __dadd_rn(__dadd_rn(l0, l1), __dadd_rn(l2, l3));
+        tab[(size_t)s * N + pos] = __dadd_rn(__dadd_rn(l0, l1), __dadd_rn(l2, l3));
     }
 }
 
 size_t leaf_table_doubles(const iqhip_engine *e) { return (size_t)e->ncat * e->state_unknown * e->n; }
 
-hipError_t launch_leaf_tables(iqhip_engine *e, int nops) {
-    if (nops <= 0) return hipSuccess;
-    const int n = e->n, rows = e->state_unknown;
-    const size_t lds = (size_t)(n * (n + 1) + rows * n) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_leaf_tables), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_leaf_tables, dim3((unsigned)(nops * 2 * e->ncat)), dim3(256), lds, e->stream, e->d_ops, n, e->ncat,
-                       rows, e->d_eval, e->d_evec, e->d_rates, e->d_tip);
+hipError_t launch_leaf_tables(iqhip_engine *e, const TabJob *d_jobs, int njobs) {
+    if (njobs <= 0) return hipSuccess;
+    const int rows = e->state_unknown;
+    const int nsplit = e->n >= 64 ? 4 : 1;
+    const int per = (rows + nsplit - 1) / nsplit;
+    const size_t lds = (size_t)per * e->n * sizeof(double);
+    const dim3 grid((unsigned)(njobs * e->ncat * nsplit));
+    if (e->n == 64)
+        hipLaunchKernelGGL(k_leaf_tables<64>, grid, dim3(256), lds, e->stream, d_jobs, e->ncat, rows, nsplit, e->d_eval,
+                           e->d_evec, e->d_rates, e->d_tip);
+    else if (e->n == 20)
+        hipLaunchKernelGGL(k_leaf_tables<20>, grid, dim3(256), lds, e->stream, d_jobs, e->ncat, rows, nsplit, e->d_eval,
+                           e->d_evec, e->d_rates, e->d_tip);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -309,6 +318,10 @@ hipError_t launch_leaf_tables(iqhip_engine *e, int nops) {
 // TAB: LEAF children are table look-ups (k_leaf_tables) instead of U * (ex .* tip) products on the matrix pipe.
 template <int N, int C, int WG, int CS = 1, bool TAB = false>
 __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
+    // TABPF: the table rows of a step are requested one (op, category) step ahead (20 states: a category step is
+    // only 15 MFMAs long, too short to cover an L2 round trip; 64 states: the step is the whole op and the 2 x 16
+    // extra registers would spill, so the rows are requested at the start of the step itself)
+    constexpr bool TABPF = TAB && (N < 64);
     // rows of U / U^-1: MTF full 16-row tiles on v_mfma_f64_16x16x4_f64 plus, for N = 20, the four
     // left-over rows on v_mfma_f64_4x4x4_4b_f64 (4 blocks = the tile's 4 groups of 4 patterns).
     // Lane layouts of the 4x4x4 form (measured, tools/mfma444_probe.hip): A[i][k] at lane
@@ -391,6 +404,18 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
         for (int s = 0; s < KS; s++) PFn[s] = src[s * 64 + lane];
         if (g == 0) pfn_sc = f.pf_sc[(f.real_mask & 1) ? ptn : (int64_t)p];
         if (TAB) { sLn = f.sl[ptn]; sRn = f.sr[ptn]; }
+    }
+    v4f64 nL[MTF], nR[MTF];   // TABPF: table rows of the coming step
+    double nL4 = 0.0, nR4 = 0.0;
+#pragma unroll
+    for (int m = 0; m < MTF; m++) { nL[m] = (v4f64){0, 0, 0, 0}; nR[m] = (v4f64){0, 0, 0, 0}; }
+    if (TABPF) {
+        const CONST_AS DevOp &f = ops[k_begin];
+        const double *rl = f.tabL + ((size_t)coff * S + (sLn < S ? sLn : 0)) * N + 4 * g;
+        const double *rr = f.tabR + ((size_t)coff * S + (sRn < S ? sRn : 0)) * N + 4 * g;
+#pragma unroll
+        for (int m = 0; m < MTF; m++) { nL[m] = *reinterpret_cast<const v4f64 *>(rl + 16 * m); nR[m] = *reinterpret_cast<const v4f64 *>(rr + 16 * m); }
+        if (TAIL4) { nL4 = rl[16 * MTF - 3 * g]; nR4 = rr[16 * MTF - 3 * g]; }
     }
 
     int k = k_begin;
@@ -532,11 +557,33 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
                 };
                 // TAB: a leaf child's product is its pattern's row of the (L2-resident) table: requested before the
                 // other child's MFMA chain, multiplied in after it
-                auto table_row = [&](const double *row, v4f64 (&Y)[MTF], double &y4) {
-                    const double *r = row + (size_t)(coff + c) * S * N;
+                v4f64 cL[MTF], cR[MTF];   // TABPF: this step's rows (requested one step ago)
+                double cL4 = 0.0, cR4 = 0.0;
+                if constexpr (TABPF) {
 #pragma unroll
-                    for (int m = 0; m < MTF; m++) Y[m] = *reinterpret_cast<const v4f64 *>(r + 16 * m);
-                    if (TAIL4) y4 = r[16 * MTF - 3 * g];   // (row carries +4g: tail row 16*MTF + g)
+                    for (int m = 0; m < MTF; m++) { cL[m] = nL[m]; cR[m] = nR[m]; }
+                    cL4 = nL4; cR4 = nR4;
+                    // request the next step's rows: (k, c+1) or (k+1, 0); non-leaf children point at a valid dummy
+                    const CONST_AS DevOp &nq = (c + 1 < C) ? op : nxop;
+                    const int nsL = (c + 1 < C) ? sL : sLn, nsR = (c + 1 < C) ? sR : sRn;
+                    const int cn = (c + 1 < C) ? c + 1 : 0;
+                    const double *rl = nq.tabL + ((size_t)(coff + cn) * S + (nsL < S ? nsL : 0)) * N + 4 * g;
+                    const double *rr = nq.tabR + ((size_t)(coff + cn) * S + (nsR < S ? nsR : 0)) * N + 4 * g;
+#pragma unroll
+                    for (int m = 0; m < MTF; m++) { nL[m] = *reinterpret_cast<const v4f64 *>(rl + 16 * m); nR[m] = *reinterpret_cast<const v4f64 *>(rr + 16 * m); }
+                    if (TAIL4) { nL4 = rl[16 * MTF - 3 * g]; nR4 = rr[16 * MTF - 3 * g]; }
+                }
+                auto table_row = [&](bool right, v4f64 (&Y)[MTF], double &y4) {
+                    if constexpr (TABPF) {
+#pragma unroll
+                        for (int m = 0; m < MTF; m++) Y[m] = right ? cR[m] : cL[m];
+                        y4 = right ? cR4 : cL4;
+                    } else {
+                        const double *r = (right ? rowR : rowL) + (size_t)(coff + c) * S * N;
+#pragma unroll
+                        for (int m = 0; m < MTF; m++) Y[m] = *reinterpret_cast<const v4f64 *>(r + 16 * m);
+                        if (TAIL4) y4 = r[16 * MTF - 3 * g];   // (row carries +4g: tail row 16*MTF + g)
+                    }
                 };
                 if (!TAB || (!leafL && !leafR)) {
                     v4f64 YR[MTF];
@@ -548,14 +595,14 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
                 } else if (leafL && leafR) {
                     v4f64 YR[MTF];
                     double yr4 = 0.0;
-                    table_row(rowL, T, t4);
-                    table_row(rowR, YR, yr4);
+                    table_row(false, T, t4);
+                    table_row(true, YR, yr4);
                     chain(F_{}, F_{}, T, YR, t4, yr4);   // (only refills the prefetch registers)
                     hadamard(YR, yr4, unkL, unkR);
                 } else if (leafL) {
                     v4f64 YR[MTF];
                     double yr4 = 0.0;
-                    table_row(rowL, T, t4);
+                    table_row(false, T, t4);
 #pragma unroll
                     for (int m = 0; m < MTF; m++) YR[m] = (v4f64){0, 0, 0, 0};
                     chain(F_{}, T_{}, YR, YR, yr4, yr4);
@@ -563,7 +610,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
                 } else {
                     v4f64 YL[MTF];
                     double yl4 = 0.0;
-                    table_row(rowR, T, t4);
+                    table_row(true, T, t4);
 #pragma unroll
                     for (int m = 0; m < MTF; m++) YL[m] = (v4f64){0, 0, 0, 0};
                     chain(T_{}, F_{}, YL, YL, yl4, yl4);
