@@ -877,6 +877,8 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
             std::fill(e->tab_len.begin(), e->tab_len.end(), NAN);
             e->tab_model_version = e->model_version;
         }
+        // non-leaf children point at slot 0: the kernels may request a row unconditionally (one step ahead)
+        for (int k = 0; k < nops; k++) e->h_ops[k].tabL = e->h_ops[k].tabR = e->d_leaf_tab;
         for (size_t q = 0; q < uses.size(); q++) {
             DevOp &d = e->h_ops[uses[q].first];
             (uses[q].second ? d.tabR : d.tabL) = e->d_leaf_tab + (size_t)use_slot[q] * per;
