@@ -91,6 +91,8 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     }
     e->own_stream = true;
     if (const char *ab = getenv("IQHIP_ABLATE")) e->ablate = atoi(ab);
+    if (const char *h = getenv("IQHIP_HOLD")) e->use_hold = atoi(h) != 0;
+    if (const char *f = getenv("IQHIP_FOLD")) e->fold_reduce = atoi(f) != 0;
     if (const char *sp = getenv("IQHIP_SPLIT")) e->split_target = atoi(sp);
     if (const char *kb = getenv("IQHIP_LDS_KB")) {
         int v = atoi(kb);
@@ -131,8 +133,11 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
             e->num_cus = cus;
         ok = dmalloc(&e->d_newton_partials, (size_t)4 * e->num_cus) == hipSuccess &&
-             dmalloc(&e->d_newton_barrier, 2) == hipSuccess;
+             dmalloc(&e->d_newton_barrier, 2) == hipSuccess && dmalloc(&e->d_fold_ticket, 4) == hipSuccess &&
+             dmalloc(&e->d_fold_flags, (size_t)e->result_cap) == hipSuccess;
         if (ok) hipMemsetAsync(e->d_newton_barrier, 0, 2 * sizeof(unsigned int), e->stream);
+        if (ok) hipMemsetAsync(e->d_fold_ticket, 0, 4 * sizeof(unsigned int), e->stream);
+        if (ok) hipMemsetAsync(e->d_fold_flags, 0, (size_t)e->result_cap * sizeof(int), e->stream);
         if (!ok) {
             iqhip_destroy(e);
             return fail(IQHIP_ERR_NOMEM, "iqhip_create: device allocation failed");
@@ -184,7 +189,7 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
     }
     void *ptrs[] = {e->d_states, e->d_freq, e->d_invar, e->d_model, e->d_ops, e->d_slab,
                     e->d_theta, e->d_pattern_lh, e->d_leaf_tab, e->dummy.plh, e->dummy.sc, e->d_newton_partials,
-                    e->d_newton_barrier, e->d_ptn_scaled, e->d_boot, e->d_img, e->d_theta_batch, e->d_batch_partials,
+                    e->d_newton_barrier, e->d_fold_ticket, e->d_fold_flags, e->d_ptn_scaled, e->d_boot, e->d_img, e->d_theta_batch, e->d_batch_partials,
                     e->d_batch_out, e->d_batch_barriers, e->d_batch_tasks};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -792,7 +797,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
     // HOLD analysis (4-state kernel): a streamed left child produced by op j of this plan can stay
     // in registers until its join k if no op in (j, k) streams, loads or parks anything itself
     // (the usual case after heavier-first ordering: the other subtree is a short chain).
-    if (!e->mfma && !(e->ablate & 4)) {
+    if (!e->mfma && !(e->ablate & 4) && (e->use_hold || e->lane_split != 1 || e->wg_size != 256)) {
         std::unordered_map<const double *, int> producer;
         for (int k = 0; k < nops; k++) {
             DevOp &d = e->h_ops[k];
@@ -1050,13 +1055,18 @@ static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, 
         }
     }
     const bool empty_top = e->plan_nunits > 0 && !has_root && e->plan_top_nops == 0;  // explicit segments only
+    // the submission's last kernel sums the wave partials itself (FoldArgs) where it can: the 4-state traversal
+    // (its top-stage launch) and the matrix-core path's root-branch kernel; otherwise a k_reduce launch follows
+    const bool fold4 = e->fold_reduce && !e->mfma && !empty_top && !skip_reduce && e->wg_size == 256;
+    const bool foldm = e->fold_reduce && e->mfma && has_root && e->n_unobs == 0;
     if (empty_top) {
     } else if (e->mfma) HIPCHK(launch_traverse_mfma(e, table, nops > 0 ? 1 : 0, nwaves));
-    else HIPCHK(launch_traverse4(e, table, 1, e->plan_has_load, has_root ? &br : nullptr, nwaves));
+    else HIPCHK(launch_traverse4(e, table, 1, e->plan_has_load, has_root ? &br : nullptr, nwaves, fold4 ? nops : -1));
     timing_end(e);
     if (e->timing) e->tev_launches += (int)e->plan_stage_units.size() + (empty_top ? 0 : 1);
-    if (e->mfma && has_root) HIPCHK(launch_stream_mfma(e, 0, &br, br.len, nwaves));
-    if (has_root) HIPCHK(launch_reduce(e, 0, 2 + nops, nwaves));
+    if (e->mfma && has_root) HIPCHK(launch_stream_mfma(e, 0, &br, br.len, nwaves, nullptr, foldm ? nops : -1));
+    if (fold4 || foldm) {
+    } else if (has_root) HIPCHK(launch_reduce(e, 0, 2 + nops, nwaves));
     else if (!skip_reduce) HIPCHK(launch_reduce(e, 2, nops, nwaves));
     e->last_nops = nops;
     return IQHIP_OK;

@@ -158,6 +158,7 @@ struct iqhip_engine {
     bool row_split = false; // 64 states, 1 category: one wave per 16 output rows of a tile (small alignments)
     bool cat_split = false; // 20 states, 4 categories: one wave per category of a tile (small alignments)
     int lane_split = 1;    // 4-state traversal: lanes per pattern (2: each lane owns half of the categories)
+    bool use_hold = true;  // 4-state traversal: park join operands in a second register set (IQHIP_HOLD)
     int ablate = 0;        // IQHIP_ABLATE: timing-only host-side switches (results wrong when set)
     int lds_budget_bytes = 64 * 1024;  // per-workgroup LDS for the per-branch regions (IQHIP_LDS_KB)
     int plan_lds_doubles = 0;
@@ -200,6 +201,9 @@ struct iqhip_engine {
     int ops_cap = 0;
     double *d_slab = nullptr;   // wave partials [nvals][nwaves]
     int64_t slab_cap = 0;
+    unsigned int *d_fold_ticket = nullptr;  // folded reduction (FoldArgs): ticket + per-row flags, zero between launches
+    int *d_fold_flags = nullptr;
+    bool fold_reduce = true;                // IQHIP_FOLD=0: always the separate k_reduce launch
     double *d_theta = nullptr, *d_pattern_lh = nullptr;
     // K2 tables of the leaf children (matrix-core pipelined kernels, kernels_mfma.hip k_leaf_tables).  A table depends
     // on (model, pendant branch length) only, so slot t < ntaxa belongs to taxon t and is rebuilt only when that
@@ -284,6 +288,75 @@ struct iqhip_engine {
 
 namespace iqhip {
 
+// ---------------------------------------------------------------------------------------------------------------
+// Reduction folded into the producing kernel ("last workgroup sums"): every wave leaves its partial sums in the slab
+// [row][wave]; rows: 0 = lnL (or df), 1 = prob_const (or ddf), 2+k = sum_scale of node update k.  sum_scale rows are
+// zero unless some pattern was rescaled at that node, so a wave that did rescale also raises flags[row]; the last
+// workgroup to finish sums row 0/1 and the flagged rows in k_reduce's order (same bits) and writes 0.0 for the rest.
+// Hand-off between workgroups (MI355X_MICROARCH.md, valid forms): partials are agent-scope (sc1, write-through)
+// stores, each wave drains them (s_waitcnt vmcnt(0)) before the workgroup barrier, one lane then takes a ticket with
+// an agent-scope atomic; the workgroup that draws the last ticket reads with agent-scope (sc1) loads.
+// ---------------------------------------------------------------------------------------------------------------
+struct FoldArgs {
+    double *slab;          // [rows][nwaves]
+    double *result;        // result[row]
+    unsigned int *ticket;  // zero between launches
+    int *flags;            // [rows], zero between launches
+    int nwaves;
+    int nrows_scale;       // sum_scale rows (2 .. 2+nrows_scale)
+    int root_rows;         // 0: none; 2: rows 0 and 1 hold the root-branch sums
+    int enabled;
+};
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ void fold_store(double *p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void fold_flag(const FoldArgs &F, int row) {
+    __hip_atomic_fetch_or(&F.flags[row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// all live threads of a 256-thread workgroup call this once, after their last partial has been stored
+__device__ inline void fold_tail(const FoldArgs &F) {
+    __shared__ double s_f[256];
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(F.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int nrows = 2 + F.nrows_scale;
+    for (int row = F.root_rows ? 0 : 2; row < nrows; row++) {
+        bool live = row < 2;
+        if (!live) live = __hip_atomic_load(&F.flags[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;  // uniform
+        if (!live) {
+            if (threadIdx.x == 0) F.result[row] = 0.0;
+            continue;
+        }
+        const double *r = F.slab + (size_t)row * F.nwaves;
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < F.nwaves; i += 256)
+            acc += __hip_atomic_load(&r[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_f[threadIdx.x] = acc;
+        __syncthreads();
+#pragma unroll
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) s_f[threadIdx.x] += s_f[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            F.result[row] = s_f[0];
+            if (row >= 2) __hip_atomic_store(&F.flags[row], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(F.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
 // engine.hip: records the calling thread's error text (iqhip_last_error) and returns `code`
 int set_error(int code, const std::string &msg);
 
@@ -337,7 +410,10 @@ int synchronize(iqhip_engine *p);
 
 // kernels_valu4.hip
 // seg_table: device ints {begin, nops} x nsegs; every segment runs on its own set of workgroups
-hipError_t launch_traverse4(iqhip_engine *e, const int *seg_table, int nsegs, bool has_load, const DevBranch *root, int nwaves);
+// fold_rows >= 0: this is the submission's last launch and it sums the slab itself (rows 2 .. 2+fold_rows, plus 0/1
+// with a root branch) instead of a k_reduce launch
+hipError_t launch_traverse4(iqhip_engine *e, const int *seg_table, int nsegs, bool has_load, const DevBranch *root, int nwaves,
+                            int fold_rows = -1);
 hipError_t launch_theta4(iqhip_engine *e, const DevBranch &br);
 hipError_t launch_derv4(iqhip_engine *e, double len, int nwaves, const NewtonState *st = nullptr);
 hipError_t launch_lnl_theta4(iqhip_engine *e, double len, int nwaves);
@@ -375,6 +451,6 @@ size_t leaf_table_doubles(const iqhip_engine *e);          // doubles per (leaf 
 int mfma2_fixed_lds_doubles(int n);
 // mode 0: branch lnL, 1: theta, 2: df/ddf from theta, 3: lnL from theta
 hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, double len, int nwaves,
-                              const NewtonState *st = nullptr);
+                              const NewtonState *st = nullptr, int fold_rows = -1);
 
 }  // namespace iqhip

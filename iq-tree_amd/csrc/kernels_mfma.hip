@@ -69,6 +69,7 @@ struct TravMArgs {
     int nwaves;
     int ncat;
     int state_unknown;
+    int *fold_flags;        // per result row: raised by a wave that rescaled patterns at that node (FoldArgs::flags)
 };
 
 // LDS image index of A[m][s][lane]
@@ -219,7 +220,10 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
             }
             if (g == 0) op.dst_sc[ptn] = (int16_t)sc;
             const double ws = wave_sum_m(my_scale);
-            if (lane == 0) A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
+            if (lane == 0) {
+                A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
+                if (ws != 0.0) __hip_atomic_fetch_or(&A.fold_flags[2 + op.out_row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -686,7 +690,10 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
             prev_sc = sc;
             if (lead && g == 0) op.dst_sc[ptn] = (int16_t)sc;
             const double ws = wave_sum_m(my_scale);
-            if (lead && lane == 0) A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
+            if (lead && lane == 0) {
+                A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
+                if (ws != 0.0) __hip_atomic_fetch_or(&A.fold_flags[2 + op.out_row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -853,7 +860,10 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_mix20(const TravMArgs A
             }
             if (lead && g == 0) op.dst_sc[ptn] = (int16_t)sc;
             const double ws = wave_sum_m(my_scale);
-            if (lead && lane == 0) A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
+            if (lead && lane == 0) {
+                A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
+                if (ws != 0.0) __hip_atomic_fetch_or(&A.fold_flags[2 + op.out_row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -1041,7 +1051,10 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_rows64(const TravMArgs 
             prev_sc = sc;
             if (lead && g == 0) op.dst_sc[ptn] = (int16_t)sc;
             const double ws = wave_sum_m(my_scale);
-            if (lead && lane == 0) A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
+            if (lead && lane == 0) {
+                A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
+                if (ws != 0.0) __hip_atomic_fetch_or(&A.fold_flags[2 + op.out_row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -1110,6 +1123,7 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs
     A.nwaves = nwaves;
     A.ncat = e->ncat;
     A.state_unknown = e->state_unknown;
+    A.fold_flags = e->d_fold_flags;
     if (nsegs <= 0) return hipSuccess;
     if (e->mfma_pipelined) {  // plan was built in canonical (PF, PREV) form
         if (e->plan_nleaf_tabs > 0 || e->leaf_tables) {  // leaf children from the K2 tables (k_leaf_tables)
@@ -1165,6 +1179,7 @@ struct StreamMArgs {
     int ncat;
     double len;
     const NewtonState *st;    // a step of the enqueued Newton chain: len = st->rts, nothing to do once st->done
+    FoldArgs fold;            // the last workgroup sums the slab itself (no k_reduce launch)
 };
 
 template <int MODE>
@@ -1240,8 +1255,8 @@ __global__ __launch_bounds__(256) void k_stream_mfma(const StreamMArgs A) {
         const double ddfp = fma(-dfp, dfp, d2 * inv);
         const double wa = wave_sum_m(mine ? dfp * f : 0.0), wb = wave_sum_m(mine ? ddfp * f : 0.0);
         if (lane == 0) {
-            A.slab[tile] = wa;
-            A.slab[(size_t)A.nwaves + tile] = wb;
+            fold_store(&A.slab[tile], wa);
+            fold_store(&A.slab[(size_t)A.nwaves + tile], wb);
         }
         if (asc) {  // phylokernel.h:655-725
             const double w2 = wave_sum_m(unobs ? lhi : 0.0), w3 = wave_sum_m(unobs ? d1 : 0.0),
@@ -1265,16 +1280,25 @@ __global__ __launch_bounds__(256) void k_stream_mfma(const StreamMArgs A) {
         const double wa = wave_sum_m(mine ? plh * f : 0.0);
         const double wpc = asc ? wave_sum_m(pc) : 0.0;
         if (lane == 0) {
-            A.slab[tile] = wa;
-            A.slab[(size_t)A.nwaves + tile] = wpc;
+            fold_store(&A.slab[tile], wa);
+            fold_store(&A.slab[(size_t)A.nwaves + tile], wpc);
         }
     }
+    if (A.fold.enabled) fold_tail(A.fold);
 }
 
 hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, double len, int nwaves,
-                              const NewtonState *st) {
+                              const NewtonState *st, int fold_rows) {
     StreamMArgs A;
     A.st = st;
+    A.fold.slab = e->d_slab;
+    A.fold.result = e->d_result;
+    A.fold.ticket = e->d_fold_ticket;
+    A.fold.flags = e->d_fold_flags;
+    A.fold.nwaves = nwaves;
+    A.fold.nrows_scale = fold_rows > 0 ? fold_rows : 0;
+    A.fold.root_rows = 2;
+    A.fold.enabled = (fold_rows >= 0 && mode != 1 && e->n_unobs == 0) ? 1 : 0;
     if (br) A.br = *br; else A.br = DevBranch{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.0};
     A.tip = e->d_tipc;
     A.eval = e->d_evalc;

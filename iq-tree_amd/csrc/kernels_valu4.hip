@@ -99,6 +99,7 @@ struct Trav4Args {
     int lds_reg_doubles;  // size of the per-branch region area (largest chunk)
     int nsegs_launch;     // host side only: segments of this launch, instantiation choice
     int has_load;
+    FoldArgs fold;
     DevBranch root;
 };
 
@@ -138,13 +139,13 @@ __device__ __forceinline__ void leaf_cat4(const double *reg /* [ex B][table 5B] 
 // op k+1's streamed child (nx_pf), so the prefetch needs no second register set and no copy.
 // Returns lh_max (0 for LEAF-LEAF, which the reference never rescales).
 // With SP = 2 lanes per pattern a lane owns C = CF/2 of the block's CF categories, starting at `coff`.
-template <int C, int CF>
+template <int C, int CF, bool USE_HOLD>
 __device__ __forceinline__ double node_update4(bool leafL, bool holdL, bool leafR, const double *regL,
                                                const double *regR, const double *s_tip,
                                                const CONST_AS double *U, const CONST_AS double *uinv,
                                                int sL, int sR, int state_unknown, const char *nx_pf,
-                                               char *dst, int coff, double (&PF)[4 * C], const double (&HOLD)[4 * C],
-                                               double (&prev)[4 * C]) {
+                                               char *dst, int coff, double (&PF)[4 * C],
+                                               const double (&HOLD)[USE_HOLD ? 4 * C : 1], double (&prev)[4 * C]) {
     bool slowL = false, slowR = false;
     int rowL = 0, rowR = 0;
     if (leafL) {
@@ -163,9 +164,9 @@ __device__ __forceinline__ double node_update4(bool leafL, bool holdL, bool leaf
             leaf_cat4<CF>(regL, s_tip, U, sL, rowL, slowL, state_unknown, coff + c, a);
         } else {
             double l[4];
-            if (holdL) {
+            if (USE_HOLD && holdL) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) l[i] = regL[(coff + c) * 4 + i] * HOLD[c * 4 + i];
+                for (int i = 0; i < 4; i++) l[i] = regL[(coff + c) * 4 + i] * HOLD[USE_HOLD ? c * 4 + i : 0];
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; i++) l[i] = regL[(coff + c) * 4 + i] * PF[c * 4 + i];
@@ -248,7 +249,8 @@ __device__ __forceinline__ void store_vec4_off(double *base, uint32_t voff, cons
 // categories, so a small alignment yields twice as many waves with half the register state each (the
 // 4-state kernel is latency / occupancy limited below ~4 waves per SIMD).  The memory layout is
 // unchanged: the lane's categories are rows [2*coff, 2*coff + 2*CL) of the tile.
-template <int C, int WG, bool HAS_LOAD, int SP>
+// USE_HOLD = false: no HOLD register set (the plan then contains no CHILD_HOLD / push_hold): 2*BL fewer registers
+template <int C, int WG, bool HAS_LOAD, int SP, bool USE_HOLD = true>
 __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
     static_assert(SP == 1 || (SP == 2 && C % 2 == 0), "SP = 2 needs an even category count");
     constexpr int B = 4 * C;
@@ -294,11 +296,13 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
     const CONST_AS double *uinv = as_const(A.inv_evec);
     const CONST_AS DevOp *ops = as_const(A.ops);
 
-    double prev[BL], PF[BL], HOLD[BL];
+    double prev[BL], PF[BL], HOLD[USE_HOLD ? BL : 1];
     int hold_sc = 0;
     int pf_sc = 0, prev_sc = 0;
 #pragma unroll
-    for (int e = 0; e < BL; e++) { prev[e] = 0.0; PF[e] = 0.0; HOLD[e] = 0.0; }
+    for (int e = 0; e < BL; e++) { prev[e] = 0.0; PF[e] = 0.0; }
+#pragma unroll
+    for (int e = 0; e < (USE_HOLD ? BL : 1); e++) HOLD[e] = 0.0;
 
     // everything op k needs from memory is requested while op k-1 computes.  Prime for op 0.
     // (ops[nops] is a sentinel whose pointers are valid dummies, so the requests are unconditional)
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
         for (int kk = 0; kk < kn; kk++, k++) {
             const CONST_AS DevOp *op = ops + k;
             const bool leafL = op->left_kind == CHILD_LEAF;
-            const bool holdL = op->left_kind == CHILD_HOLD;
+            const bool holdL = USE_HOLD && op->left_kind == CHILD_HOLD;
             const bool leafR = op->right_kind == CHILD_LEAF;
             int sc = 0;
             // leaf states were staged into LDS when the chunk was filled
@@ -382,8 +386,8 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
             pf_sc = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(nx->pf_sc) +
                                                        ((nreal & 1) ? soff : (uint32_t)(lane * 2)));
             char *dstp = reinterpret_cast<char *>(op->dst) + voff;
-            double lh_max = node_update4<CL, C>(leafL, holdL, leafR, s_reg + op->lds_left, s_reg + op->lds_right,
-                                                s_tip, U, uinv, sL, sR, A.state_unknown, nx_pf, dstp, coff, PF, HOLD, prev);
+            double lh_max = node_update4<CL, C, USE_HOLD>(leafL, holdL, leafR, s_reg + op->lds_left, s_reg + op->lds_right,
+                                                          s_tip, U, uinv, sL, sR, A.state_unknown, nx_pf, dstp, coff, PF, HOLD, prev);
             if (SP == 2) lh_max = fmax(lh_max, __shfl_xor(lh_max, 32, 64));  // both category halves of the pattern
             // ---- scaling (SIMD rule, phylokernel.h:379-392,461-474); TIP-TIP never scales
             const bool do_scale = !(leafL && leafR) && (lh_max < kScalingThreshold) && (invar == 0.0) && !op->no_scale;
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
                 }
             }
             prev_sc = sc;
-            if (op->push_hold) {
+            if (USE_HOLD && op->push_hold) {
                 // this result is the left child of a join a few ops ahead whose other subtree is a
                 // plain chain: park it in registers instead of re-reading 8 KiB per wave from memory
 #pragma unroll
@@ -414,11 +418,14 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
             // deterministic reduction: wave partial -> slab[2+k][gw]
             double ws = 0.0;
             if (any) ws = wave_sum(my_scale);
-            if (lane == 0) A.slab[(size_t)(2 + op->out_row) * A.nwaves + gw] = ws;
+            if (lane == 0) {
+                fold_store(&A.slab[(size_t)(2 + op->out_row) * A.nwaves + gw], ws);
+                if (any) fold_flag(A.fold, 2 + op->out_row);
+            }
         }
     }
     if (k_end == k_begin) __syncthreads();  // s_tip / s_val visibility for a root-only launch
-    if (!active) return;
+    if (!active) return;   // (an exited wave no longer takes part in workgroup barriers)
 
     if (A.has_root) {
         // ---- branch lnL, phylokernel.h:806-838 (leaf form) / :930-956 (internal form)
@@ -465,27 +472,39 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
         const double ws = wave_sum(acc);
         const double wpc = (A.nobs < A.nptn) ? wave_sum(pc) : 0.0;
         if (lane == 0) {
-            A.slab[gw] = ws;
-            A.slab[(size_t)A.nwaves + gw] = wpc;
+            fold_store(&A.slab[gw], ws);
+            fold_store(&A.slab[(size_t)A.nwaves + gw], wpc);
         }
+    }
+    if constexpr (WG == 256) {
+        if (A.fold.enabled) fold_tail(A.fold);
     }
 }
 
-template <int C, int WG, bool HAS_LOAD, int SP>
-static hipError_t launch_trav_l(iqhip_engine *e, Trav4Args &A) {
+template <int C, int WG, bool HAS_LOAD, int SP, bool USE_HOLD>
+static hipError_t launch_trav_h(iqhip_engine *e, Trav4Args &A) {
     constexpr int B = 4 * C;
     const size_t lds = (size_t)(128 + B + (size_t)e->plan_lds_doubles) * sizeof(double) +
                        (size_t)e->plan_state_slots * WG;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse4<C, WG, HAS_LOAD, SP>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse4<C, WG, HAS_LOAD, SP, USE_HOLD>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     constexpr int WPB = WG / 64;
     A.ngroups = (int)((e->ntiles * SP + WPB - 1) / WPB);
-    hipLaunchKernelGGL((k_traverse4<C, WG, HAS_LOAD, SP>), dim3((unsigned)(A.ngroups * A.nsegs_launch)), dim3(WG), lds, e->stream, A);
+    hipLaunchKernelGGL((k_traverse4<C, WG, HAS_LOAD, SP, USE_HOLD>), dim3((unsigned)(A.ngroups * A.nsegs_launch)), dim3(WG), lds, e->stream, A);
     return hipGetLastError();
+}
+
+template <int C, int WG, bool HAS_LOAD, int SP>
+static hipError_t launch_trav_l(iqhip_engine *e, Trav4Args &A) {
+    // (only the default workgroup size is instantiated both ways)
+    if constexpr (WG == 256 && SP == 1) {
+        if (!e->use_hold) return launch_trav_h<C, WG, HAS_LOAD, SP, false>(e, A);
+    }
+    return launch_trav_h<C, WG, HAS_LOAD, SP, true>(e, A);
 }
 
 template <int C, int WG>
@@ -506,8 +525,17 @@ static hipError_t launch_trav_wg(iqhip_engine *e, Trav4Args &A) {
     }
 }
 
-hipError_t launch_traverse4(iqhip_engine *e, const int *seg_table, int nsegs, bool has_load, const DevBranch *root, int nwaves) {
+hipError_t launch_traverse4(iqhip_engine *e, const int *seg_table, int nsegs, bool has_load, const DevBranch *root, int nwaves,
+                            int fold_rows) {
     Trav4Args A;
+    A.fold.slab = e->d_slab;
+    A.fold.result = e->d_result;
+    A.fold.ticket = e->d_fold_ticket;
+    A.fold.flags = e->d_fold_flags;
+    A.fold.nwaves = nwaves;
+    A.fold.nrows_scale = fold_rows > 0 ? fold_rows : 0;
+    A.fold.root_rows = root ? 2 : 0;
+    A.fold.enabled = (fold_rows >= 0 && e->wg_size == 256) ? 1 : 0;
     A.ops = e->d_ops;
     A.evec = e->d_evec;
     A.inv_evec = e->d_inv_evec;
