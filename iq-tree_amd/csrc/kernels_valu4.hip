@@ -489,7 +489,7 @@ static hipError_t launch_trav_h(iqhip_engine *e, Trav4Args &A) {
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse4<C, WG, HAS_LOAD, SP, USE_HOLD>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);  // (160 KB minus the static arrays of fold_tail)
         attr_set = true;
     }
     constexpr int WPB = WG / 64;
