@@ -336,15 +336,25 @@ __device__ inline void fold_tail(const FoldArgs &F) {
             if (threadIdx.x == 0) F.result[row] = 0.0;
             continue;
         }
+        // k_reduce's order: 256 strided running sums, then the LDS tree.  Only wave 0 is certain to be alive (the
+        // workgroup's trailing waves have exited when the tile count is not a multiple of four), so its 64 lanes
+        // stand in for the 256 threads; the other live waves only keep the barriers company.
         const double *r = F.slab + (size_t)row * F.nwaves;
-        double acc = 0.0;
-        for (int i = threadIdx.x; i < F.nwaves; i += 256)
-            acc += __hip_atomic_load(&r[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_f[threadIdx.x] = acc;
+        if (threadIdx.x < 64) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int v = (int)threadIdx.x + 64 * j;
+                double acc = 0.0;
+                for (int i = v; i < F.nwaves; i += 256)
+                    acc += __hip_atomic_load(&r[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_f[v] = acc;
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int o = 128; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) s_f[threadIdx.x] += s_f[threadIdx.x + o];
+            if (threadIdx.x < 64)
+                for (int v = (int)threadIdx.x; v < o; v += 64) s_f[v] += s_f[v + o];
             __syncthreads();
         }
         if (threadIdx.x == 0) {
