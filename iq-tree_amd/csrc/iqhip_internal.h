@@ -328,17 +328,13 @@ __device__ inline void fold_tail(const FoldArgs &F) {
     }
     __syncthreads();
     if (!s_last) return;
+    // Only wave 0 is certain to be alive (the workgroup's trailing waves have exited when the tile count is not a
+    // multiple of four), so its 64 lanes do the work; the other live waves only keep the barriers company.
+    __shared__ int s_rows[256];
+    __shared__ int s_n;
     const int nrows = 2 + F.nrows_scale;
-    for (int row = F.root_rows ? 0 : 2; row < nrows; row++) {
-        bool live = row < 2;
-        if (!live) live = __hip_atomic_load(&F.flags[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;  // uniform
-        if (!live) {
-            if (threadIdx.x == 0) F.result[row] = 0.0;
-            continue;
-        }
-        // k_reduce's order: 256 strided running sums, then the LDS tree.  Only wave 0 is certain to be alive (the
-        // workgroup's trailing waves have exited when the tile count is not a multiple of four), so its 64 lanes
-        // stand in for the 256 threads; the other live waves only keep the barriers company.
+    // one row: k_reduce's order -- 256 strided running sums (lane = 4 of them), then the LDS tree
+    auto sum_row = [&](int row) {
         const double *r = F.slab + (size_t)row * F.nwaves;
         if (threadIdx.x < 64) {
 #pragma unroll
@@ -357,11 +353,34 @@ __device__ inline void fold_tail(const FoldArgs &F) {
                 for (int v = (int)threadIdx.x; v < o; v += 64) s_f[v] += s_f[v + o];
             __syncthreads();
         }
-        if (threadIdx.x == 0) {
-            F.result[row] = s_f[0];
-            if (row >= 2) __hip_atomic_store(&F.flags[row], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) F.result[row] = s_f[0];
+        __syncthreads();
+    };
+    if (F.root_rows) {
+        sum_row(0);
+        sum_row(1);
+    }
+    // sum_scale rows, 256 at a time: the lanes look at the flags side by side, unflagged rows are 0.0 at once
+    for (int base = 2; base < nrows; base += 256) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = base + (int)threadIdx.x + 64 * j;
+                if (row < nrows) {
+                    if (__hip_atomic_load(&F.flags[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        s_rows[atomicAdd(&s_n, 1)] = row;
+                        __hip_atomic_store(&F.flags[row], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        F.result[row] = 0.0;
+                    }
+                }
+            }
         }
         __syncthreads();
+        const int n = s_n;
+        for (int q = 0; q < n; q++) sum_row(s_rows[q]);
     }
     if (threadIdx.x == 0) __hip_atomic_store(F.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
