@@ -203,7 +203,13 @@ struct iqhip_engine {
     int64_t slab_cap = 0;
     unsigned int *d_fold_ticket = nullptr;  // folded reduction (FoldArgs): ticket + per-row flags, zero between launches
     int *d_fold_flags = nullptr;
-    bool fold_reduce = true;                // IQHIP_FOLD=0: always the separate k_reduce launch
+    bool fold_reduce = false;               // IQHIP_FOLD=1: the last kernel of a submission sums the slab itself (measured
+                                            // slower than the k_reduce launch on MI355X; off by default)
+    // host polling of the result (IQHIP_POLL): k_reduce's last block stores a sequence number to mapped host memory
+    bool poll_result = true, poll_pending = false;
+    unsigned long long result_seq = 0;
+    volatile unsigned long long *h_done = nullptr;
+    unsigned long long *d_done = nullptr;
     double *d_theta = nullptr, *d_pattern_lh = nullptr;
     // K2 tables of the leaf children (matrix-core pipelined kernels, kernels_mfma.hip k_leaf_tables).  A table depends
     // on (model, pendant branch length) only, so slot t < ntaxa belongs to taxon t and is rebuilt only when that

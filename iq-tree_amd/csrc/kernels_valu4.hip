@@ -731,8 +731,12 @@ hipError_t launch_lnl_theta4(iqhip_engine *e, double len, int nwaves) {
 // ---------------------------------------------------------------------------------------
 // fixed-order reduction of the wave partials: block v sums slab[v][0..nwaves) -> result[v]
 // ---------------------------------------------------------------------------------------
+// done != nullptr: the result vector is mapped host memory and the host polls it instead of paying a stream
+// synchronisation (engine.hip read_result): every block publishes its row with a system-scope fence and takes a ticket;
+// the block that draws the last one stores the sequence number the host is waiting for.
 __global__ __launch_bounds__(256) void k_reduce(const double *__restrict__ slab, int nwaves,
-                                                int first_row, double *__restrict__ result) {
+                                                int first_row, double *__restrict__ result, unsigned int *ticket,
+                                                volatile unsigned long long *done, unsigned long long seq) {
     __shared__ double s[256];
     const double *row = slab + (size_t)(first_row + blockIdx.x) * nwaves;
     double acc = 0.0;
@@ -744,13 +748,31 @@ __global__ __launch_bounds__(256) void k_reduce(const double *__restrict__ slab,
         if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) result[first_row + blockIdx.x] = s[0];
+    if (threadIdx.x == 0) {
+        result[first_row + blockIdx.x] = s[0];
+        if (done) {
+            __threadfence_system();
+            const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == gridDim.x - 1) {
+                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence_system();
+                *done = seq;
+            }
+        }
+    }
 }
 
 hipError_t launch_reduce(iqhip_engine *e, int first_row, int nrows, int nwaves) {
     if (nrows <= 0) return hipSuccess;
+    unsigned long long *done = nullptr;
+    unsigned long long seq = 0;
+    if (e->poll_result && e->d_result == e->d_result_own) {  // mapped host memory: the host may poll
+        seq = ++e->result_seq;
+        done = e->d_done;
+        e->poll_pending = true;
+    }
     hipLaunchKernelGGL(k_reduce, dim3(nrows), dim3(256), 0, e->stream, e->d_slab, nwaves,
-                       first_row, e->d_result);
+                       first_row, e->d_result, e->d_fold_ticket + 1, done, seq);
     return hipGetLastError();
 }
 
