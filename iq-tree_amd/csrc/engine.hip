@@ -93,6 +93,7 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     e->own_stream = true;
     if (const char *ab = getenv("IQHIP_ABLATE")) e->ablate = atoi(ab);
     if (const char *h = getenv("IQHIP_HOLD")) e->use_hold = atoi(h) != 0;
+    if (const char *h = getenv("IQHIP_MIXED_TOP")) e->mixed_top = atoi(h) != 0;
     if (const char *f = getenv("IQHIP_FOLD")) e->fold_reduce = atoi(f) != 0;
     if (const char *f = getenv("IQHIP_POLL")) e->poll_result = atoi(f) != 0;
     if (const char *sp = getenv("IQHIP_SPLIT")) e->split_target = atoi(sp);
@@ -911,9 +912,11 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         int budget;
         if (e->mfma) {
             const int MT = (e->n + 15) / 16, KS = e->n / 4;
-            const int fixed = (e->row_split && e->mfma_pipelined) ? (e->state_unknown + 1) * e->n + 4 * 16 * 64 + 128
+            int fixed = (e->row_split && e->mfma_pipelined) ? (e->state_unknown + 1) * e->n + 4 * 16 * 64 + 128
                               : (e->mfma_pipelined ? mfma2_fixed_lds_doubles(e->n) : 2 * MT * KS * 64) +
                                     (e->state_unknown + 1 - e->n) * e->n;
+            // (64 states: a launch may mix both roles, k_traverse_mfma_top64)
+            if (e->mfma_pipelined && e->n == 64) fixed = std::max(fixed, (e->state_unknown + 1) * e->n + 4 * 16 * 64 + 128);
             // two workgroups per CU (160 KB LDS): <= 78 KB each, images included (a third workgroup
             // for the 20-state kernel was measured: no gain, more chunks); IQHIP_MFMA_LDS_KB overrides
             int total_kb = 78;
@@ -1066,7 +1069,7 @@ static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, 
     const bool fold4 = e->fold_reduce && !e->mfma && !empty_top && !skip_reduce && e->wg_size == 256;
     const bool foldm = e->fold_reduce && e->mfma && has_root && e->n_unobs == 0;
     if (empty_top) {
-    } else if (e->mfma) HIPCHK(launch_traverse_mfma(e, table, nops > 0 ? 1 : 0, nwaves));
+    } else if (e->mfma) HIPCHK(launch_traverse_mfma(e, table, nops > 0 ? 1 : 0, nwaves, /*top_stage=*/true));
     else HIPCHK(launch_traverse4(e, table, 1, e->plan_has_load, has_root ? &br : nullptr, nwaves, fold4 ? nops : -1));
     timing_end(e);
     if (e->timing) e->tev_launches += (int)e->plan_stage_units.size() + (empty_top ? 0 : 1);

@@ -158,6 +158,7 @@ struct iqhip_engine {
     bool row_split = false; // 64 states, 1 category: one wave per 16 output rows of a tile (small alignments)
     bool cat_split = false; // 20 states, 4 categories: one wave per category of a tile (small alignments)
     int lane_split = 1;    // 4-state traversal: lanes per pattern (2: each lane owns half of the categories)
+    bool mixed_top = true; // 64 states: mixed-role top stage (kernels_mfma.hip k_traverse_mfma_top64; IQHIP_MIXED_TOP)
     bool use_hold = true;  // 4-state traversal: park join operands in a second register set (IQHIP_HOLD)
     int ablate = 0;        // IQHIP_ABLATE: timing-only host-side switches (results wrong when set)
     int lds_budget_bytes = 64 * 1024;  // per-workgroup LDS for the per-branch regions (IQHIP_LDS_KB)
@@ -480,7 +481,7 @@ size_t newton_task_bytes();
 void newton_task_fill(void *dst, const DevBranch &br, double xguess, double x1, double x2, double xacc, int max_steps);
 
 // kernels_mfma.hip (nstates 20 / 64)
-hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs, int nwaves);
+hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs, int nwaves, bool top_stage = false);
 hipError_t launch_leaf_tables(iqhip_engine *e, const TabJob *d_jobs, int njobs);
 size_t leaf_table_doubles(const iqhip_engine *e);          // doubles per (leaf child) table: ncat * state_unknown * n
 int mfma2_fixed_lds_doubles(int n);

@@ -22,6 +22,7 @@
 // This first version reads both children from memory (L2/MALL-resident after an earlier op of
 // the same launch); keeping the previous result in registers as in the DNA kernel is the next
 // optimisation step.
+#include <algorithm>
 #include <type_traits>
 
 #include "iqhip_internal.h"
@@ -320,8 +321,8 @@ hipError_t launch_leaf_tables(iqhip_engine *e, const TabJob *d_jobs, int njobs) 
 // small alignment yields CS times the waves with 1/CS of the dependent MFMA chain per op; the only cross-wave step is
 // the scaling maximum of a pattern (LDS + one workgroup barrier per op).
 // TAB: LEAF children are table look-ups (k_leaf_tables) instead of U * (ex .* tip) products on the matrix pipe.
-template <int N, int C, int WG, int CS = 1, bool TAB = false>
-__global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
+template <int N, int C, int WG, int CS, bool TAB>
+__device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vblock) {
     // TABPF: the table rows of a step are requested one (op, category) step ahead (20 states: a category step is
     // only 15 MFMAs long, too short to cover an L2 round trip; 64 states: the step is the whole op and the 2 x 16
     // extra registers would spill, so the rows are requested at the start of the step itself)
@@ -374,9 +375,9 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int seg = (int)blockIdx.x / A.ngroups;  // scalar
+    const int seg = vblock / A.ngroups;  // scalar
     const int k_begin = as_const(A.segs)[2 * seg], k_end = k_begin + as_const(A.segs)[2 * seg + 1];
-    const int64_t tile = (int64_t)((int)blockIdx.x - seg * A.ngroups) * (WPB / CS) + wave / CS;
+    const int64_t tile = (int64_t)(vblock - seg * A.ngroups) * (WPB / CS) + wave / CS;
     const int coff = (wave % CS) * C;          // first category of this wave
     const bool lead = (wave % CS) == 0;        // the wave that owns the tile's counters and sums
     const bool active = tile < A.ntiles;
@@ -698,6 +699,11 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
     }
 }
 
+template <int N, int C, int WG, int CS = 1, bool TAB = false>
+__global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
+    trav_mfma2_body<N, C, WG, CS, TAB>(A, (int)blockIdx.x);
+}
+
 template <int N, bool MIX>
 static hipError_t launch_trav_m(iqhip_engine *e, TravMArgs &A) {
     constexpr int MT = (N + 15) / 16, KS = N / 4, WG = 256;
@@ -900,8 +906,9 @@ static hipError_t launch_trav_mix20(iqhip_engine *e, TravMArgs &A) {
 // LDS as B-operand k-step slices (the accumulator image of M-tile w IS k-steps 4w..4w+3), one workgroup barrier
 // each; the scaling maximum takes a third.  Same canonical plan form as k_traverse_mfma2 (C = 1).
 // ---------------------------------------------------------------------------------------
+// tile0: first tile of this role (the mixed top-stage kernel gives the row-split role the tiles behind the full ones)
 template <int WG, bool TAB>
-__global__ __launch_bounds__(WG, 2) void k_traverse_mfma_rows64(const TravMArgs A) {
+__device__ __forceinline__ void trav_rows64_body(const TravMArgs &A, const int vblock, const int64_t tile0) {
     constexpr int N = 64, KS = 16, B = 64;
     static_assert(WG == 256, "one tile per workgroup of four waves");
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -915,9 +922,9 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_rows64(const TravMArgs 
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int seg = (int)blockIdx.x / A.ngroups;  // scalar
+    const int seg = vblock / A.ngroups;  // scalar
     const int k_begin = as_const(A.segs)[2 * seg], k_end = k_begin + as_const(A.segs)[2 * seg + 1];
-    const int64_t tile = (int64_t)((int)blockIdx.x - seg * A.ngroups);
+    const int64_t tile = tile0 + (int64_t)(vblock - seg * A.ngroups);
     const bool active = tile < A.ntiles;          // uniform over the workgroup
     const int64_t tl = active ? tile : 0;
     const int p = lane & 15, g = lane >> 4;
@@ -1059,6 +1066,25 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_rows64(const TravMArgs 
     }
 }
 
+template <int WG, bool TAB>
+__global__ __launch_bounds__(WG, 2) void k_traverse_mfma_rows64(const TravMArgs A) {
+    trav_rows64_body<WG, TAB>(A, (int)blockIdx.x, 0);
+}
+
+// ---------------------------------------------------------------------------------------
+// 64 states, the sequential top stage of a staged plan, MIXED roles.  A tile's op list is one wave's dependent chain,
+// so an alignment with slightly more tiles than the chip has SIMDs (20 000 codon patterns = 1250 tiles on 1024 SIMDs)
+// leaves most SIMDs with one chain and a fifth of them with two -- the launch takes as long as two chains although
+// the chip is 61 % loaded.  Here the first `nfull` workgroups walk four tiles each as k_traverse_mfma2 does (one chain
+// per SIMD when nfull = number of CUs) and every tile beyond those gets a workgroup of its own whose four waves own 16
+// of the 64 output rows each (k_traverse_mfma_rows64): a quarter chain per SIMD, placed beside the full chains.
+// ---------------------------------------------------------------------------------------
+template <bool TAB>
+__global__ __launch_bounds__(256, 2) void k_traverse_mfma_top64(const TravMArgs A, const int nfull, const TravMArgs R) {
+    if ((int)blockIdx.x < nfull) trav_mfma2_body<64, 1, 256, 1, TAB>(A, (int)blockIdx.x);
+    else trav_rows64_body<256, TAB>(R, (int)blockIdx.x - nfull, (int64_t)nfull * 4);
+}
+
 template <bool TAB>
 static hipError_t launch_trav_rows64(iqhip_engine *e, TravMArgs &A) {
     constexpr int WG = 256;
@@ -1100,7 +1126,29 @@ static hipError_t launch_trav_m2(iqhip_engine *e, TravMArgs &A) {
     return hipGetLastError();
 }
 
-hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs, int nwaves) {
+// the mixed-role top stage (k_traverse_mfma_top64): full-chain workgroups for whole rounds of the chip, row-split
+// workgroups for the tiles that are left over
+template <bool TAB>
+static hipError_t launch_trav_top64(iqhip_engine *e, TravMArgs &A, int nfull) {
+    const int nx = e->state_unknown + 1 - 64;
+    const size_t fixed = std::max<size_t>((size_t)mfma2_fixed_lds_doubles(64) + (size_t)nx * 64, (size_t)(64 + nx) * 64 + 4 * 16 * 64);
+    const size_t lds = (fixed + e->plan_lds_doubles) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma_top64<TAB>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    TravMArgs F = A, R = A;
+    F.ntiles = (int64_t)nfull * 4;
+    F.ngroups = nfull;
+    R.ngroups = (int)(A.ntiles - F.ntiles);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((k_traverse_mfma_top64<TAB>), dim3((unsigned)(nfull + R.ngroups)), dim3(256), lds, e->stream, F, nfull, R);
+    return hipGetLastError();
+}
+
+hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs, int nwaves, bool top_stage) {
     TravMArgs A;
     A.ops = e->d_ops;
     A.evec = e->d_evec;
@@ -1125,6 +1173,15 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs
     A.state_unknown = e->state_unknown;
     A.fold_flags = e->d_fold_flags;
     if (nsegs <= 0) return hipSuccess;
+    if (e->mfma_pipelined && top_stage && nsegs == 1 && e->n == 64 && e->ncat == 1 && !e->row_split && e->mixed_top) {
+        // whole rounds of one chain per SIMD go to full-chain workgroups, a small remainder to row-split ones
+        const int64_t per_round = (int64_t)e->num_cus * 4;
+        const int64_t rounds = e->ntiles / per_round, rest = e->ntiles - rounds * per_round;
+        if (rounds >= 1 && rest > 0 && rest <= per_round / 2) {
+            const int nfull = (int)(rounds * e->num_cus);
+            return (e->plan_nleaf_tabs > 0 || e->leaf_tables) ? launch_trav_top64<true>(e, A, nfull) : launch_trav_top64<false>(e, A, nfull);
+        }
+    }
     if (e->mfma_pipelined) {  // plan was built in canonical (PF, PREV) form
         if (e->plan_nleaf_tabs > 0 || e->leaf_tables) {  // leaf children from the K2 tables (k_leaf_tables)
             if (e->n == 20 && e->ncat == 4)
