@@ -510,36 +510,60 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
                             for (int s = 0; s < KS; s++) br[s] = (s < 4 * MTF) ? prev[c][(s >> 2) < MTF ? (s >> 2) : 0][s & 3] : prevT[c];
                         }
                     }
+                    // A fragments of U for the k-step after this one are fetched before this one's MFMAs are issued
+                    // (STREAM keeps the k-steps in program order, so nothing else would cover the LDS latency)
+                    double aC[MTF], exlC = 0.0, exrC = 0.0;
+                    if constexpr (STREAM) {
+#pragma unroll
+                        for (int m = 0; m < MTF; m++) aC[m] = sU[aidx<KS>(m, 0, lane)];
+                        if (doL) exlC = exL[(coff + c) * N + g];
+                        if (doR) exrC = exR[(coff + c) * N + g];
+                    }
 #pragma unroll
                     for (int s = 0; s < KS; s++) {
                         const int i = 4 * s + g;
                         double vl = 0.0, vr = 0.0;
+                        double aN[MTF], exlN = 0.0, exrN = 0.0;
                         if constexpr (STREAM) {
                             if (doL) vl = (!TAB && leafL) ? tip_at(sL, i) : PFn[s];
                             PFn[s] = nsrc[s * 64 + lane];
                             if (doR) vr = (!TAB && leafR) ? tip_at(sR, i)
                                                           : ((s < 4 * MTF) ? prev[c][(s >> 2) < MTF ? (s >> 2) : 0][s & 3] : prevT[c]);
+                            if (s + 1 < KS) {
+#pragma unroll
+                                for (int m = 0; m < MTF; m++) aN[m] = sU[aidx<KS>(m, s + 1, lane)];
+                                if (doL) exlN = exL[(coff + c) * N + i + 4];
+                                if (doR) exrN = exR[(coff + c) * N + i + 4];
+                            }
                         } else {
                             vl = bl[s];
                             vr = br[s];
                         }
                         if constexpr (doL) {
-                            const double xl = vl * exL[(coff + c) * N + i];
+                            const double xl = vl * (STREAM ? exlC : exL[(coff + c) * N + i]);
 #pragma unroll
                             for (int m = 0; m < MTF; m++)
-                                YL[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(sU[aidx<KS>(m, s, lane)], xl, YL[m], 0, 0, 0);
+                                YL[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(STREAM ? aC[m] : sU[aidx<KS>(m, s, lane)], xl, YL[m], 0, 0, 0);
                             if (TAIL4) yl4 = __builtin_amdgcn_mfma_f64_4x4x4f64(sU4[s * 64 + lane], xl, yl4, 0, 0, 0);
                         }
                         if constexpr (doR) {
-                            const double xr = vr * exR[(coff + c) * N + i];
+                            const double xr = vr * (STREAM ? exrC : exR[(coff + c) * N + i]);
 #pragma unroll
                             for (int m = 0; m < MTF; m++)
-                                YR[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(sU[aidx<KS>(m, s, lane)], xr, YR[m], 0, 0, 0);
+                                YR[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(STREAM ? aC[m] : sU[aidx<KS>(m, s, lane)], xr, YR[m], 0, 0, 0);
                             if (TAIL4) yr4 = __builtin_amdgcn_mfma_f64_4x4x4f64(sU4[s * 64 + lane], xr, yr4, 0, 0, 0);
                         }
                         // 64 states: keep the k-steps in program order, or the scheduler hoists all 16 operand
                         // fetches above the first MFMA and the kernel spills
-                        if constexpr (STREAM) __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (STREAM) {
+                            if (s + 1 < KS) {
+#pragma unroll
+                                for (int m = 0; m < MTF; m++) aC[m] = aN[m];
+                                exlC = exlN;
+                                exrC = exrN;
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 };
                 using T_ = std::true_type;
