@@ -390,6 +390,20 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
     const CONST_AS DevOp *ops = as_const(A.ops);
     const int S = A.state_unknown;                // rows of a leaf table
 
+    // AREG (20 states): the A fragments of U and U^-1 (16-row tile + 4-row tail: 4 x 5 doubles) stay in registers for
+    // the whole launch; with them in LDS every k-step of every chain waited for an LDS round trip before its MFMAs
+    constexpr bool AREG = (N < 64);
+    double aU[AREG ? KS : 1], aU4[AREG ? KS : 1], aUi[AREG ? KS : 1], aUi4[AREG ? KS : 1];
+    if constexpr (AREG) {
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const int k4 = 4 * s + (lane >> 4);
+            aU[s] = A.evec[(lane & 15) * N + k4];
+            aUi[s] = A.inv_evec[(lane & 15) * N + k4];
+            aU4[s] = TAIL4 ? A.evec[(16 * MTF + (lane & 3)) * N + k4] : 0.0;
+            aUi4[s] = TAIL4 ? A.inv_evec[(16 * MTF + (lane & 3)) * N + k4] : 0.0;
+        }
+    }
     v4f64 prev[C][MTF];
     double prevT[C];  // tail rows 16*MTF+g
 #pragma unroll
@@ -493,7 +507,13 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
                 auto chain = [&](auto DOL, auto DOR, v4f64 (&YL)[MTF], v4f64 (&YR)[MTF], double &yl4, double &yr4) {
                     constexpr bool doL = decltype(DOL)::value, doR = decltype(DOR)::value;
                     double bl[STREAM ? 1 : KS], br[STREAM ? 1 : KS];
+                    double exl[STREAM ? 1 : KS], exr[STREAM ? 1 : KS];   // the chain's exponentials, fetched together
                     if constexpr (!STREAM) {
+#pragma unroll
+                        for (int s = 0; s < KS; s++) {
+                            exl[s] = doL ? exL[(coff + c) * N + 4 * s + g] : 0.0;
+                            exr[s] = doR ? exR[(coff + c) * N + 4 * s + g] : 0.0;
+                        }
 #pragma unroll
                         for (int s = 0; s < KS; s++) bl[s] = PFn[s];
 #pragma unroll
@@ -540,18 +560,18 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
                             vr = br[s];
                         }
                         if constexpr (doL) {
-                            const double xl = vl * (STREAM ? exlC : exL[(coff + c) * N + i]);
+                            const double xl = vl * (STREAM ? exlC : exl[STREAM ? 0 : s]);
 #pragma unroll
                             for (int m = 0; m < MTF; m++)
-                                YL[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(STREAM ? aC[m] : sU[aidx<KS>(m, s, lane)], xl, YL[m], 0, 0, 0);
-                            if (TAIL4) yl4 = __builtin_amdgcn_mfma_f64_4x4x4f64(sU4[s * 64 + lane], xl, yl4, 0, 0, 0);
+                                YL[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(STREAM ? aC[m] : (AREG ? aU[AREG ? s : 0] : sU[aidx<KS>(m, s, lane)]), xl, YL[m], 0, 0, 0);
+                            if (TAIL4) yl4 = __builtin_amdgcn_mfma_f64_4x4x4f64(AREG ? aU4[AREG ? s : 0] : sU4[s * 64 + lane], xl, yl4, 0, 0, 0);
                         }
                         if constexpr (doR) {
-                            const double xr = vr * (STREAM ? exrC : exR[(coff + c) * N + i]);
+                            const double xr = vr * (STREAM ? exrC : exr[STREAM ? 0 : s]);
 #pragma unroll
                             for (int m = 0; m < MTF; m++)
-                                YR[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(STREAM ? aC[m] : sU[aidx<KS>(m, s, lane)], xr, YR[m], 0, 0, 0);
-                            if (TAIL4) yr4 = __builtin_amdgcn_mfma_f64_4x4x4f64(sU4[s * 64 + lane], xr, yr4, 0, 0, 0);
+                                YR[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(STREAM ? aC[m] : (AREG ? aU[AREG ? s : 0] : sU[aidx<KS>(m, s, lane)]), xr, YR[m], 0, 0, 0);
+                            if (TAIL4) yr4 = __builtin_amdgcn_mfma_f64_4x4x4f64(AREG ? aU4[AREG ? s : 0] : sU4[s * 64 + lane], xr, yr4, 0, 0, 0);
                         }
                         // 64 states: keep the k-steps in program order, or the scheduler hoists all 16 operand
                         // fetches above the first MFMA and the kernel spills
@@ -656,8 +676,8 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
                     const double bt = (s < 4 * MTF) ? T[(s >> 2) < MTF ? (s >> 2) : 0][s & 3] : t4;
 #pragma unroll
                     for (int m = 0; m < MTF; m++)
-                        O[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(sUi[aidx<KS>(m, s, lane)], bt, O[m], 0, 0, 0);
-                    if (TAIL4) o4 = __builtin_amdgcn_mfma_f64_4x4x4f64(sUi4[s * 64 + lane], bt, o4, 0, 0, 0);
+                        O[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(AREG ? aUi[AREG ? s : 0] : sUi[aidx<KS>(m, s, lane)], bt, O[m], 0, 0, 0);
+                    if (TAIL4) o4 = __builtin_amdgcn_mfma_f64_4x4x4f64(AREG ? aUi4[AREG ? s : 0] : sUi4[s * 64 + lane], bt, o4, 0, 0, 0);
                 }
 #pragma unroll
                 for (int m = 0; m < MTF; m++) {
