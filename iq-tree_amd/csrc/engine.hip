@@ -381,8 +381,23 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
     if (e->aln_set && state_unknown != e->state_unknown)
         return fail(IQHIP_ERR_INVALID, "iqhip_set_model: state_unknown changed after set_alignment");
     if (nclass < 1 || nclass > e->ncat) return fail(IQHIP_ERR_INVALID, "bad number of mixture classes");
-    if (nclass > 1 && e->n != 20)
-        return fail(IQHIP_ERR_UNSUPPORTED, "mixture models are implemented for 20 states (matrix-core kernel) only");
+    // Mixtures: 20 states have a kernel of their own (k_traverse_mfma_mix20); 64 and 4 states take the generic
+    // matrix-core kernel with per-class A images.  A 4-state engine therefore changes its vector layout (64-pattern
+    // tiles of the VALU kernels <-> 16-pattern tiles of the matrix-core kernels) when the model becomes / stops being
+    // a mixture; as with every model change the caller invalidates all vectors (clearAllPartialLH).
+    if (e->n == 4) {
+        const bool want_mfma = nclass > 1;
+        if (want_mfma != e->mfma) {
+            HIPCHK(hipSetDevice(e->device));
+            HIPCHK(hipStreamSynchronize(e->stream));
+            e->mfma = want_mfma;
+            e->tile = want_mfma ? 16 : 64;
+            e->ntiles = e->nptn_pad / e->tile;
+            e->uploaded_plan.clear();
+            e->last_plan_version = 0;
+            e->theta_valid = false;
+        }
+    }
     std::vector<int> cls(e->ncat, 0);
     if (nclass > 1) {
         if (!cat_class) return fail(IQHIP_ERR_INVALID, "null argument");
@@ -437,7 +452,7 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
         // (16-row tile: row = lane & 15; 4-row tail: row = 16 + (lane & 3); k = 4s + (lane >> 4)), followed by
         // the padded two-tile images [class][U | U^-1][m][s][lane] of the generic kernel (IQHIP_MIX_GENERIC)
         const int MT = (n + 15) / 16, KS = n / 4;
-        const size_t mix_doubles = (size_t)nclass * 4 * KS * 64;
+        const size_t mix_doubles = (size_t)nclass * 4 * KS * 64;  // (only read by the 20-state kernel)
         std::vector<double> img(mix_doubles + (size_t)nclass * 2 * MT * KS * 64, 0.0);
         for (int m = 0; m < nclass; m++) {
             const double *U = evec + (size_t)m * n * n, *Ui = inv_evec + (size_t)m * n * n;
@@ -445,8 +460,10 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
                 for (int l = 0; l < 64; l++) {
                     const int k = 4 * s + (l >> 4), r16 = l & 15, r4 = 16 + (l & 3);
                     double *b = &img[(size_t)m * 4 * KS * 64];
-                    b[(0 * KS + s) * 64 + l] = U[r16 * n + k];
-                    b[(2 * KS + s) * 64 + l] = Ui[r16 * n + k];
+                    if (r16 < n) {
+                        b[(0 * KS + s) * 64 + l] = U[r16 * n + k];
+                        b[(2 * KS + s) * 64 + l] = Ui[r16 * n + k];
+                    }
                     if (r4 < n) {
                         b[(1 * KS + s) * 64 + l] = U[r4 * n + k];
                         b[(3 * KS + s) * 64 + l] = Ui[r4 * n + k];

@@ -1246,7 +1246,8 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs
             // with one class (16+4-row MFMA split, A fragments in registers) beats the padded generic kernel
             if (e->d_img && !getenv("IQHIP_MIX_GENERIC")) return launch_trav_mix20(e, A);
             return launch_trav_m<20, false>(e, A);
-        case 64: return launch_trav_m<64, false>(e, A);
+        case 64: return e->nclass > 1 ? launch_trav_m<64, true>(e, A) : launch_trav_m<64, false>(e, A);
+        case 4: return launch_trav_m<4, true>(e, A);  // 4-state mixtures (a plain 4-state model never comes here)
         default: return hipErrorInvalidValue;
     }
 }

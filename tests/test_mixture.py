@@ -108,15 +108,50 @@ def test_mixture_model_switching_and_limits(pkg, synth, oracle):
         ot = oracle.OracleTree(nwk, 20, 1, pat, freq, None, model)
         ref, _ = ot.likelihood()
         assert abs(t.compute_likelihood() - ref) <= LNL_RTOL * abs(ref)
-    # 4-state mixtures are not implemented on the device: loud error, no fallback
-    m4 = synth.mixture_model(4, 2, 5, ncat=2)
-    st4 = synth.simulate_alignment(nwk, m4.classes[0], 50, 6)
-    p4, f4 = synth.compress_patterns(st4)
-    t4 = pkg.PhyloTree(nwk)
-    t4.set_alignment(4, 0, p4, f4)
-    t4.set_model(m4)
-    with pytest.raises(pkg.HostError, match="20 states"):
-        t4.attach_engine(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,seq_type,nclass,ncat,fused,ntaxa,nsites,kw", [
+    (4, 0, 2, 4, False, 14, 900, dict()),                                       # DNA mixture x Gamma: 8 components
+    (4, 0, 3, 1, True, 10, 400, dict()),                                        # fused mixture-rate model
+    (4, 0, 2, 2, False, 120, 200, dict(lo=0.4, hi=0.9, caterpillar=True)),      # with scaling events
+    (64, 2, 2, 1, True, 9, 300, dict()),                                        # codon mixture (M-series style classes)
+    (64, 2, 3, 2, False, 7, 150, dict()),
+])
+def test_hip_mixtures_of_4_and_64_states(pkg, synth, oracle, n, seq_type, nclass, ncat, fused, ntaxa, nsites, kw):
+    """phylokernelmixture.h / phylokernelmixrate.h as bound for 4 and 64 states (phylotreeavx.cpp:62-73, 107-121): the
+    generic matrix-core kernel with per-class A images; a 4-state engine switches to the 16-pattern tile layout while
+    its model is a mixture and back when it is not."""
+    from test_parity_gpu import check_all_vectors, LNL_RTOL
+    model, nwk, pat, freq, ot = make_mix(synth, oracle, n, nclass, ncat, fused, ntaxa, nsites, 900 + n + nclass + ntaxa,
+                                         seq_type, **kw)
+    t = pkg.PhyloTree(nwk)
+    t.set_alignment(n, seq_type, pat, freq)
+    t.set_model(model)
+    t.attach_engine(0)
+    lnl = t.compute_likelihood()
+    ref, (a, b) = ot.likelihood()
+    assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+    assert check_all_vectors(t, ot) == ntaxa - 2
+    if kw:
+        assert ot.partial(a, b)[1].max() >= 1 if not ot.is_leaf(b) else ot.partial(b, a)[1].max() >= 1
+    df, ddf = t.compute_likelihood_derv(a, b)
+    rdf, rddf = ot.derv(a, b)
+    assert abs(ddf - rddf) <= 1e-8 * abs(rddf) and abs(df - rdf) <= 1e-8 * max(abs(rdf), 1e-3 * abs(rddf))
+    assert abs(t.compute_likelihood_from_buffer() - ref) <= LNL_RTOL * abs(ref)
+    before = t.compute_likelihood()
+    x, y = [(x, y) for x in range(t.num_nodes) for y, _ in t.neighbors(x) if x < y][3]
+    t.optimize_one_branch(x, y)
+    assert t.compute_likelihood() >= before - 1e-9 * abs(before)
+    if n == 4:
+        # back to a plain model on the same engine (64-pattern tiles again), then to the mixture once more
+        plain = synth.gtr_model(ncat=model.ncat)
+        for m2 in (plain, model):
+            t.set_model(m2)
+            t.clear_all_partial_lh()
+            o2 = oracle.OracleTree(nwk, 4, 0, pat, freq, None, m2)
+            r2, _ = o2.likelihood()
+            assert abs(t.compute_likelihood() - r2) <= LNL_RTOL * abs(r2)
 
 
 @pytest.mark.gpu
