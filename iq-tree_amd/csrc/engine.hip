@@ -391,6 +391,8 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
             HIPCHK(hipSetDevice(e->device));
             HIPCHK(hipStreamSynchronize(e->stream));
             e->mfma = want_mfma;
+            if (want_mfma) { e->lane_split_valu = e->lane_split; e->lane_split = 1; }  // (a VALU-kernel notion)
+            else e->lane_split = e->lane_split_valu;
             e->tile = want_mfma ? 16 : 64;
             e->ntiles = e->nptn_pad / e->tile;
             e->uploaded_plan.clear();

@@ -158,6 +158,7 @@ struct iqhip_engine {
     bool row_split = false; // 64 states, 1 category: one wave per 16 output rows of a tile (small alignments)
     bool cat_split = false; // 20 states, 4 categories: one wave per category of a tile (small alignments)
     int lane_split = 1;    // 4-state traversal: lanes per pattern (2: each lane owns half of the categories)
+    int lane_split_valu = 1;  // ... remembered while a 4-state engine runs a mixture on the matrix-core kernels
     bool mixed_top = true; // 64 states: mixed-role top stage (kernels_mfma.hip k_traverse_mfma_top64; IQHIP_MIXED_TOP)
     bool use_hold = true;  // 4-state traversal: park join operands in a second register set (IQHIP_HOLD)
     int ablate = 0;        // IQHIP_ABLATE: timing-only host-side switches (results wrong when set)
