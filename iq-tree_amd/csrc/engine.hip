@@ -94,7 +94,6 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     if (const char *ab = getenv("IQHIP_ABLATE")) e->ablate = atoi(ab);
     if (const char *h = getenv("IQHIP_HOLD")) e->use_hold = atoi(h) != 0;
     if (const char *h = getenv("IQHIP_MIXED_TOP")) e->mixed_top = atoi(h) != 0;
-    if (const char *h = getenv("IQHIP_WIDE20")) e->wide20 = atoi(h) != 0;
     if (const char *f = getenv("IQHIP_FOLD")) e->fold_reduce = atoi(f) != 0;
     if (const char *f = getenv("IQHIP_POLL")) e->poll_result = atoi(f) != 0;
     if (const char *sp = getenv("IQHIP_SPLIT")) e->split_target = atoi(sp);

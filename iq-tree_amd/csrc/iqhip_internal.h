@@ -159,7 +159,6 @@ struct iqhip_engine {
     bool cat_split = false; // 20 states, 4 categories: one wave per category of a tile (small alignments)
     int lane_split = 1;    // 4-state traversal: lanes per pattern (2: each lane owns half of the categories)
     int lane_split_valu = 1;  // ... remembered while a 4-state engine runs a mixture on the matrix-core kernels
-    bool wide20 = true;    // 20 states x 4 categories: the one-wave-per-SIMD kernel (k_traverse_mfma20w; IQHIP_WIDE20)
     bool mixed_top = true; // 64 states: mixed-role top stage (kernels_mfma.hip k_traverse_mfma_top64; IQHIP_MIXED_TOP)
     bool use_hold = true;  // 4-state traversal: park join operands in a second register set (IQHIP_HOLD)
     int ablate = 0;        // IQHIP_ABLATE: timing-only host-side switches (results wrong when set)

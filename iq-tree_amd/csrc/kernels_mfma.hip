@@ -748,252 +748,6 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
     trav_mfma2_body<N, C, WG, CS, TAB>(A, (int)blockIdx.x);
 }
 
-// ---------------------------------------------------------------------------------------
-// 20 states, WIDE form: one wave per SIMD (512 registers), all C categories of an op interleaved.
-//
-// k_traverse_mfma2<20,4> walks the categories one after the other: a category step is 15-30 MFMAs in dependent
-// chains of 5 (the 20 eigen-indices are only 5 k-steps), so with two waves per SIMD the matrix pipe sat idle half of
-// the time behind accumulator dependencies, LDS round trips and the one-step-ahead prefetch (measured: 37-60 % busy,
-// time independent of the number of MFMAs).  Here every k-step issues the MFMAs of all C categories and of both
-// children back to back (8-16 independent accumulators), the A fragments, the previous result, the NEXT op's streamed
-// child (all categories: 10 KB per wave in flight) and the NEXT op's leaf-table rows live in registers, and the leaf
-// states are requested two ops ahead.  Leaf children always come from the K2 tables (k_leaf_tables).
-// Same plan form, HBM layout, counters and sums as k_traverse_mfma2; vectors are bit-identical to it.
-// ---------------------------------------------------------------------------------------
-template <int C, int WG>
-__global__ __launch_bounds__(WG, 1) void k_traverse_mfma20w(const TravMArgs A) {
-    constexpr int N = 20, KS = 5, WPB = WG / 64, B = C * N;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *sReg = smem;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int seg = (int)blockIdx.x / A.ngroups;  // scalar
-    const int k_begin = as_const(A.segs)[2 * seg], k_end = k_begin + as_const(A.segs)[2 * seg + 1];
-    const int64_t tile = (int64_t)((int)blockIdx.x - seg * A.ngroups) * WPB + wave;
-    const bool active = tile < A.ntiles;
-    const int64_t tl = active ? tile : 0;
-    const int p = lane & 15, g = lane >> 4;
-    const int64_t ptn = tl * 16 + p;
-    const size_t tbase = (size_t)tl * 16 * B;
-    const double freq = A.freq[ptn];
-    const double invar = A.invar[ptn];
-    const CONST_AS DevOp *ops = as_const(A.ops);
-    const int S = A.state_unknown;
-
-    double aU[KS], aU4[KS], aUi[KS], aUi4[KS];
-#pragma unroll
-    for (int s = 0; s < KS; s++) {
-        const int k4 = 4 * s + (lane >> 4);
-        aU[s] = A.evec[(lane & 15) * N + k4];
-        aUi[s] = A.inv_evec[(lane & 15) * N + k4];
-        aU4[s] = A.evec[(16 + (lane & 3)) * N + k4];
-        aUi4[s] = A.inv_evec[(16 + (lane & 3)) * N + k4];
-    }
-    v4f64 prev[C];
-    double prevT[C];
-#pragma unroll
-    for (int c = 0; c < C; c++) { prev[c] = (v4f64){0, 0, 0, 0}; prevT[c] = 0.0; }
-    int prev_sc = 0, pf_sc = 0;
-    double PF[C][KS];            // the coming op's streamed child
-    v4f64 tL[C], tR[C];          // the coming op's table rows
-    double tL4[C], tR4[C];
-    int sL = 0, sR = 0, sLn = 0, sRn = 0;   // leaf states of the coming op / the one after
-    auto request_rows = [&](const CONST_AS DevOp &d, int stL, int stR) {
-        const double *rl = d.tabL + (size_t)(stL < S ? stL : 0) * N + 4 * g;
-        const double *rr = d.tabR + (size_t)(stR < S ? stR : 0) * N + 4 * g;
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            tL[c] = *reinterpret_cast<const v4f64 *>(rl + (size_t)c * S * N);
-            tL4[c] = rl[(size_t)c * S * N + 16 - 3 * g];
-            tR[c] = *reinterpret_cast<const v4f64 *>(rr + (size_t)c * S * N);
-            tR4[c] = rr[(size_t)c * S * N + 16 - 3 * g];
-        }
-    };
-    auto request_pf = [&](const CONST_AS DevOp &d) {
-        const bool real = d.real_mask & 1;
-        const double *src = d.pf + (real ? tbase : 0);
-#pragma unroll
-        for (int c = 0; c < C; c++)
-#pragma unroll
-            for (int s = 0; s < KS; s++) PF[c][s] = src[(size_t)c * N * 16 + s * 64 + lane];
-        if (g == 0) pf_sc = d.pf_sc[real ? ptn : (int64_t)p];
-    };
-    {   // prime: everything the first op needs, and the states of the second (sentinels follow the last op)
-        const CONST_AS DevOp &f = ops[k_begin];
-        sL = f.sl[ptn];
-        sR = f.sr[ptn];
-        request_pf(f);
-        request_rows(f, sL, sR);
-        const CONST_AS DevOp &f2 = ops[k_begin + 1];
-        sLn = f2.sl[ptn];
-        sRn = f2.sr[ptn];
-    }
-
-    int k = k_begin;
-    while (k < k_end) {
-        const int kn = ops[k].chunk_nops;
-        __syncthreads();
-        for (int t = threadIdx.x; t < kn * 2 * B; t += WG) {
-            const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B;
-            const CONST_AS DevOp &d = ops[k + o];
-            if ((child ? d.right_kind : d.left_kind) == CHILD_LEAF) continue;  // table children need no exponentials
-            const double len = child ? d.right_len : d.left_len;
-            sReg[(child ? d.lds_right : d.lds_left) + e] = exp(A.eval[e % N] * (A.rates[e / N] * len));
-        }
-        __syncthreads();
-        if (!active) { k += kn; continue; }
-
-        for (int kk = 0; kk < kn; kk++, k++) {
-            const CONST_AS DevOp &op = ops[k];
-            const CONST_AS DevOp &nxop = ops[k + 1];
-            const CONST_AS DevOp &nnop = ops[k + 2];
-            const bool leafL = op.left_kind == CHILD_LEAF, leafR = op.right_kind == CHILD_LEAF;
-            const double *exL = sReg + op.lds_left, *exR = sReg + op.lds_right;
-            int sc = 0;
-            if (!leafL) sc += pf_sc;
-            if (op.right_kind == CHILD_LOAD) {  // rare (PF, LOAD): the right child is read now into `prev`
-                const double *src = op.ld + tbase;
-#pragma unroll
-                for (int c = 0; c < C; c++) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) prev[c][r] = src[(size_t)c * N * 16 + r * 64 + lane];
-                    prevT[c] = src[(size_t)c * N * 16 + 4 * 64 + lane];
-                }
-                if (g == 0) prev_sc = op.ld_sc[ptn];
-            }
-            if (!leafR) sc += prev_sc;
-            const bool unkL = leafL && sL == A.state_unknown, unkR = leafR && sR == A.state_unknown;
-            const bool anyUnk = __any(unkL || unkR);
-            // leaf states of the op after next (two ops of latency cover the cold byte loads)
-            const int sLnn = nnop.sl[ptn], sRnn = nnop.sr[ptn];
-
-            // ---- the two child products, all categories side by side
-            v4f64 YL[C], YR[C];
-            double yl4[C], yr4[C];
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                YL[c] = leafL ? tL[c] : (v4f64){0, 0, 0, 0};
-                yl4[c] = leafL ? tL4[c] : 0.0;
-                YR[c] = leafR ? tR[c] : (v4f64){0, 0, 0, 0};
-                yr4[c] = leafR ? tR4[c] : 0.0;
-            }
-            auto chains = [&](auto DOL, auto DOR) {
-                constexpr bool doL = decltype(DOL)::value, doR = decltype(DOR)::value;
-#pragma unroll
-                for (int s = 0; s < KS; s++) {
-#pragma unroll
-                    for (int c = 0; c < C; c++) {
-                        const int i = c * N + 4 * s + g;
-                        if constexpr (doL) {
-                            const double xl = PF[c][s] * exL[i];
-                            YL[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aU[s], xl, YL[c], 0, 0, 0);
-                            yl4[c] = __builtin_amdgcn_mfma_f64_4x4x4f64(aU4[s], xl, yl4[c], 0, 0, 0);
-                        }
-                        if constexpr (doR) {
-                            const double xr = ((s < 4) ? prev[c][s < 4 ? s : 0] : prevT[c]) * exR[i];
-                            YR[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aU[s], xr, YR[c], 0, 0, 0);
-                            yr4[c] = __builtin_amdgcn_mfma_f64_4x4x4f64(aU4[s], xr, yr4[c], 0, 0, 0);
-                        }
-                    }
-                }
-            };
-            using T_ = std::true_type;
-            using F_ = std::false_type;
-            if (!leafL && !leafR) chains(T_{}, T_{});
-            else if (!leafL) chains(T_{}, F_{});
-            else if (!leafR) chains(F_{}, T_{});
-            // ---- the coming op's inputs: streamed child (all categories), scale counter, table rows
-            request_pf(nxop);
-            request_rows(nxop, sLn, sRn);
-            // ---- Hadamard product (an unknown state at a leaf child counts as exactly 1.0), U^-1 contraction
-            v4f64 T[C];
-            double t4[C];
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                if (anyUnk) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) T[c][r] = (unkL ? 1.0 : YL[c][r]) * (unkR ? 1.0 : YR[c][r]);
-                    t4[c] = (unkL ? 1.0 : yl4[c]) * (unkR ? 1.0 : yr4[c]);
-                } else {
-                    T[c] = YL[c] * YR[c];
-                    t4[c] = yl4[c] * yr4[c];
-                }
-            }
-            v4f64 O[C];
-            double o4[C];
-#pragma unroll
-            for (int c = 0; c < C; c++) { O[c] = (v4f64){0, 0, 0, 0}; o4[c] = 0.0; }
-#pragma unroll
-            for (int s = 0; s < KS; s++)
-#pragma unroll
-                for (int c = 0; c < C; c++) {
-                    const double bt = (s < 4) ? T[c][s < 4 ? s : 0] : t4[c];
-                    O[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aUi[s], bt, O[c], 0, 0, 0);
-                    o4[c] = __builtin_amdgcn_mfma_f64_4x4x4f64(aUi4[s], bt, o4[c], 0, 0, 0);
-                }
-            double *dst = op.dst + tbase;
-            double lmax = 0.0;
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                prev[c] = O[c];
-                prevT[c] = o4[c];
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    dst[(size_t)(c * N + 4 * r + g) * 16 + p] = O[c][r];
-                    lmax = fmax(lmax, fabs(O[c][r]));
-                }
-                dst[(size_t)(c * N + 16 + g) * 16 + p] = o4[c];
-                lmax = fmax(lmax, fabs(o4[c]));
-            }
-            lmax = fmax(lmax, __shfl_xor(lmax, 16, 64));
-            lmax = fmax(lmax, __shfl_xor(lmax, 32, 64));
-            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0) && !op.no_scale;
-            double my_scale = 0.0;
-            if (__any(do_scale)) {
-                if (do_scale) {
-#pragma unroll
-                    for (int c = 0; c < C; c++) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            prev[c][r] *= kScalingThresholdInv;
-                            dst[(size_t)(c * N + 4 * r + g) * 16 + p] = prev[c][r];
-                        }
-                        prevT[c] *= kScalingThresholdInv;
-                        dst[(size_t)(c * N + 16 + g) * 16 + p] = prevT[c];
-                    }
-                    sc += 1;
-                    if (g == 0 && ptn < A.nptn) my_scale = kLogScalingThreshold * freq;
-                }
-            }
-            prev_sc = sc;
-            if (g == 0) op.dst_sc[ptn] = (int16_t)sc;
-            const double ws = wave_sum_m(my_scale);
-            if (lane == 0) {
-                A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
-                if (ws != 0.0) __hip_atomic_fetch_or(&A.fold_flags[2 + op.out_row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            sL = sLn; sR = sRn;
-            sLn = sLnn; sRn = sRnn;
-        }
-    }
-}
-
-template <int C>
-static hipError_t launch_trav_20w(iqhip_engine *e, TravMArgs &A) {
-    constexpr int WG = 256;
-    const size_t lds = (size_t)e->plan_lds_doubles * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma20w<C, WG>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
-    }
-    A.ngroups = (int)((A.ntiles + 3) / 4);
-    (void)hipGetLastError();
-    hipLaunchKernelGGL((k_traverse_mfma20w<C, WG>), dim3((unsigned)(A.ngroups * A.nsegs_launch)), dim3(WG), lds, e->stream, A);
-    return hipGetLastError();
-}
-
 template <int N, bool MIX>
 static hipError_t launch_trav_m(iqhip_engine *e, TravMArgs &A) {
     constexpr int MT = (N + 15) / 16, KS = N / 4, WG = 256;
@@ -1474,7 +1228,6 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs
     }
     if (e->mfma_pipelined) {  // plan was built in canonical (PF, PREV) form
         if (e->plan_nleaf_tabs > 0 || e->leaf_tables) {  // leaf children from the K2 tables (k_leaf_tables)
-            if (e->n == 20 && e->ncat == 4 && !e->cat_split && e->wide20) return launch_trav_20w<4>(e, A);
             if (e->n == 20 && e->ncat == 4)
                 return e->cat_split ? launch_trav_m2<20, 1, 4, true>(e, A) : launch_trav_m2<20, 4, 1, true>(e, A);
             if (e->n == 20 && e->ncat == 1) return launch_trav_m2<20, 1, 1, true>(e, A);
