@@ -101,7 +101,10 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
         int v = atoi(kb);
         if (v >= 8 && v <= 150) e->lds_budget_bytes = v * 1024;
     }
-    e->leaf_tables = e->mfma_pipelined_ok;
+    // K2 tables for leaf children: on for 64 states (matrix-pipe bound: 0.50 -> 0.40 ms per traversal at 50 x 20k);
+    // off for 20 states, where the traversal is not bound by the MFMA count (1.08 vs 1.11 ms at 100 x 50k) and a model
+    // change would cost a table rebuild per evaluation.  IQHIP_LEAF_TABLES=0|1 overrides (tests run both).
+    e->leaf_tables = e->mfma_pipelined_ok && nstates == 64;
     if (const char *lt = getenv("IQHIP_LEAF_TABLES")) e->leaf_tables = e->mfma_pipelined_ok && atoi(lt) != 0;
     if (const char *wg = getenv("IQHIP_WG")) {
         int v = atoi(wg);

@@ -788,3 +788,46 @@ def test_row_split_gives_identical_vectors(pkg, synth, oracle, ntaxa, kw, monkey
     assert x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]) and x[3] == y[3]
     if "caterpillar" in kw:
         assert x[2].max() >= 1
+
+
+@pytest.mark.parametrize("n,ncat,seq_type,ntaxa,nptn,kw", [(20, 4, 1, 18, 900, dict(missing=0.05)), (20, 1, 1, 10, 400, dict()),
+                                                           (64, 1, 2, 12, 500, dict(missing=0.05)),
+                                                           (20, 4, 1, 110, 200, dict(lo=0.3, hi=0.7, caterpillar=True))])
+@pytest.mark.parametrize("tables", ["0", "1"])
+def test_leaf_table_variants_of_the_matrix_core_kernels(pkg, synth, oracle, n, ncat, seq_type, ntaxa, nptn, kw, tables, monkeypatch):
+    """IQHIP_LEAF_TABLES: leaf children as K2 table look-ups (k_leaf_tables; default for 64 states) or as
+    U * (ex .* tip) products on the matrix pipe (default for 20 states) -- both against the oracle, including a model
+    change and a branch-length change on the same engine (cached tables must be rebuilt, and only then)."""
+    monkeypatch.setenv("IQHIP_LEAF_TABLES", tables)
+    t, ot, model, pat, freq = make_case(synth, oracle, pkg, ntaxa, nptn, n, ncat, 8800 + n + ntaxa, seq_type=seq_type, **kw)
+    if n == 20:   # protein ambiguity states B, Z, U take their own table rows
+        rng = np.random.default_rng(3)
+        pat = pat.copy()
+        m = rng.random(pat.shape) < 0.03
+        pat[m] = rng.integers(20, 23, m.sum())
+        ot = oracle.OracleTree(t.tree_string(), n, seq_type, pat, freq, None, model)
+        t = pkg.PhyloTree(t.tree_string())
+        t.set_alignment(n, seq_type, pat, freq)
+        t.set_model(model)
+        t.attach_engine(0)
+    lnl = t.compute_likelihood()
+    ref, (a, b) = ot.likelihood()
+    assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+    assert check_all_vectors(t, ot) == ntaxa - 2
+    assert t.clear_and_compute_likelihood() == lnl              # cached plan, cached tables
+    # a pendant branch changes: exactly that leaf's table is stale
+    leaf = 3
+    nb = t.neighbors(leaf)[0][0]
+    t.set_branch_length(leaf, nb, 0.37, clear_reverse=True)
+    ot.set_length(leaf, nb, 0.37)
+    t.clear_all_partial_lh()
+    ref2, _ = ot.likelihood()
+    assert abs(t.compute_likelihood() - ref2) <= LNL_RTOL * abs(ref2)
+    # the model changes: every table is stale
+    m2 = synth.random_reversible_model(n, 4242, alpha=0.6 if ncat > 1 else None, ncat=ncat)
+    t.set_model(m2)
+    ot.set_model(m2)
+    t.clear_all_partial_lh()
+    ref3, _ = ot.likelihood()
+    assert abs(t.compute_likelihood() - ref3) <= LNL_RTOL * abs(ref3)
+    assert check_all_vectors(t, ot) == ntaxa - 2
