@@ -14,7 +14,8 @@ Workloads (iq-tree_amd/synth.py BASELINE_SHAPES):
   codon    configs[4]: 64-state 50 x 20k, 20k/N per GPU (strong scaling)
 One RCCL all-reduce (SUM, f64) of the device result vector {lnL, sum_scale per node} per step when N > 1
 (SURVEY.md 8e).  Inputs are resident in HBM before the timed region.  One JSON line on rank 0; with the default
-workload the line also carries the configs[3] / configs[4] results of the same N under "also" (--no-also skips).
+workload the line also carries the configs[3] / configs[4] results of the same N under "also" (--no-also skips), so
+that the driver's N = 1, 2, 4, 8 runs of the default command give the strong-scaling curves north_star names too.
 
 `python bench.py --gpus N` without WORLD_SIZE in the environment starts its N ranks itself (fresh child
 processes through torch.distributed.run, before this process touches a GPU).
@@ -332,7 +333,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["dna", "protein", "codon", "mixture", "dna4"], default="dna",
+    ap.add_argument("--workload", choices=["dna", "protein", "codon", "mixture", "dna4"], default=None,
                     help="dna = BASELINE configs[1] (the headline); protein / dna4 / codon = configs[2] / [3] / [4]")
     ap.add_argument("--ntaxa", type=int, default=0)
     ap.add_argument("--patterns", type=int, default=0, help="patterns per GPU (overrides the workload's count)")
@@ -340,7 +341,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true",
                     help="default workload only: skip the configs[3] (dna4) and configs[4] (codon) results under 'also'")
-    ap.add_argument("--also", action="store_true", help="add the 'also' results to a non-default workload / N = 1 run")
+    ap.add_argument("--also", action="store_true", help="add the 'also' results to a non-default workload")
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="after the timed K steps, repeat the step for this long (activity evidence; 0 = off)")
     ap.add_argument("--collective", choices=["rccl", "torch"], default="rccl",
@@ -351,6 +352,8 @@ def main():
                     help="plan subtrees in the reference's neighbour order instead of heavier-first")
     ap.add_argument("--ncat", type=int, default=0, help="rate categories (dna / protein workloads; default: the BASELINE shape)")
     args = ap.parse_args()
+    default_command = args.workload is None   # the driver's command: headline + the multi-GPU configs under "also"
+    args.workload = args.workload or "dna"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
@@ -367,7 +370,7 @@ def main():
     out = run_workload(args, D, pkg, synth, args.workload, args.steps, args.warmup, not args.no_cpu_baseline)
     # the multi-GPU configs north_star names, at this N, beside the headline (the driver runs one command per N)
     plain = not (args.ntaxa or args.patterns or args.ncat)
-    if plain and ((args.workload == "dna" and D.world > 1 and not args.no_also) or args.also):
+    if plain and ((default_command and not args.no_also) or args.also):
         also = []
         for w in ("dna4", "codon"):
             if w == args.workload:

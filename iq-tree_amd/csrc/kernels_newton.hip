@@ -159,7 +159,9 @@ __device__ __forceinline__ void wg_partial(const NewtonArgs &A, const double *th
             lh += A.invar[ptn];
             const double f = A.freq[ptn];
             if (MODE == 1) {
-                adf = fma(log(fabs(lh)), f, adf);
+                double l = log(fabs(lh));
+                if (isnan(l) || isinf(l)) l = kLogScalingThreshold * 4;  // the reference's repair, phylokernel.h:1100-1122
+                adf = fma(l, f, adf);
             } else {
                 const double inv = 1.0 / fabs(lh);
                 const double dfp = d1 * inv;

@@ -8,7 +8,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B=$GRAFT_REPO_ROOT/bench.py
-python3 $B --steps 200 --warmup 20 > $OUT/bench_dna.json 2> $OUT/bench_dna.err
+python3 $B --workload dna --steps 200 --warmup 20 > $OUT/bench_dna.json 2> $OUT/bench_dna.err
 python3 $B --workload protein --steps 100 --warmup 20 --cpu-seconds 10 > $OUT/bench_protein.json 2> $OUT/bench_protein.err
 python3 $B --workload codon --steps 200 --warmup 40 --cpu-seconds 10 > $OUT/bench_codon.json 2> $OUT/bench_codon.err
 for w in dna protein codon; do
