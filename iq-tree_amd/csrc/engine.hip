@@ -50,9 +50,11 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     *out = nullptr;
     if (nptn <= 0 || ntaxa < 2 || ncat < 1)
         return fail(IQHIP_ERR_INVALID, "iqhip_create: bad nptn/ntaxa/ncat");
+    const int nstates_user = nstates;
+    if (nstates == 2) nstates = 4;  // binary data runs on the 4-state kernels through an exact embedding (iqhip_internal.h)
     if (nstates != 4 && nstates != 20 && nstates != 64)
         return fail(IQHIP_ERR_UNSUPPORTED,
-                    "iqhip_create: nstates must be 4, 20 or 64 (the reference's SIMD dispatch cases; "
+                    "iqhip_create: nstates must be 2, 4, 20 or 64 (the reference's SIMD dispatch cases; "
                     "other counts use its scalar kernel)");
     if (nstates == 4 && !(ncat >= 1 && ncat <= 8))
         return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_create: 4-state path supports ncat in {1..8}");
@@ -73,6 +75,8 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     iqhip_engine *e = new iqhip_engine();
     e->device = device;
     e->n = nstates;
+    e->n_user = nstates_user;
+    e->embed2 = nstates_user == 2;
     e->ncat = ncat;
     e->ntaxa = ntaxa;
     e->nptn = nptn;
@@ -342,9 +346,18 @@ extern "C" int iqhip_set_alignment(iqhip_engine *e, const uint8_t *states, const
                     "iqhip_set_alignment: call iqhip_set_model first (needs state_unknown)");
     HIPCHK(hipSetDevice(e->device));
     const size_t P = (size_t)e->nptn_pad, N = (size_t)e->nptn;
-    std::vector<uint8_t> tmp((size_t)e->ntaxa * P, (uint8_t)e->state_unknown);
+    // (binary data: padding patterns and missing characters are the ambiguity set {0, 1}, never the kernels' unknown)
+    std::vector<uint8_t> tmp((size_t)e->ntaxa * P, (uint8_t)(e->embed2 ? 6 : e->state_unknown));
     for (int t = 0; t < e->ntaxa; t++) {
         const uint8_t *src = states + (size_t)t * N;
+        if (e->embed2) {
+            uint8_t *dst = tmp.data() + (size_t)t * P;
+            for (size_t p = 0; p < N; p++) {
+                if (src[p] > 2) return fail(IQHIP_ERR_INVALID, "iqhip_set_alignment: state > STATE_UNKNOWN");
+                dst[p] = src[p] == 2 ? 6 : src[p];
+            }
+            continue;
+        }
         for (size_t p = 0; p < N; p++)
             if (src[p] > e->state_unknown)
                 return fail(IQHIP_ERR_INVALID, "iqhip_set_alignment: state > STATE_UNKNOWN");
@@ -510,15 +523,40 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
     return IQHIP_OK;
 }
 
+// binary data: pad the caller's 2-state system to the 4-state one the kernels run (see iqhip_engine::embed2)
+static int set_model_binary(iqhip_engine *e, const double *eval, const double *evec, const double *inv_evec,
+                            const double *rates, const double *props, int state_unknown, const double *tip) {
+    if (!eval || !evec || !inv_evec || !rates || !props || !tip) return fail(IQHIP_ERR_INVALID, "null argument");
+    if (state_unknown != 2) return fail(IQHIP_ERR_INVALID, "iqhip_set_model: binary data has STATE_UNKNOWN = 2");
+    double ev4[4] = {eval[0], eval[1], 0.0, 0.0};
+    double U4[16] = {0}, Ui4[16] = {0};
+    for (int x = 0; x < 2; x++)
+        for (int i = 0; i < 2; i++) { U4[x * 4 + i] = evec[x * 2 + i]; Ui4[x * 4 + i] = inv_evec[x * 2 + i]; }
+    U4[10] = U4[15] = Ui4[10] = Ui4[15] = 1.0;
+    std::vector<double> tip4((size_t)19 * 4, 0.0);  // DNA-style table: rows 0, 1 = the two states, row 6 = {0, 1} = missing
+    for (int i = 0; i < 2; i++) {
+        tip4[0 * 4 + i] = tip[0 * 2 + i];
+        tip4[1 * 4 + i] = tip[1 * 2 + i];
+        tip4[6 * 4 + i] = tip[2 * 2 + i];
+    }
+    return set_model_common(e, 1, nullptr, ev4, U4, Ui4, rates, props, 18, tip4.data());
+}
+
 extern "C" int iqhip_set_model(iqhip_engine *e, const double *eval, const double *evec,
                                const double *inv_evec, const double *rates, const double *props,
                                int state_unknown, const double *tip_partial_lh) {
+    if (e && e->embed2 && e->shards.empty())
+        return set_model_binary(e, eval, evec, inv_evec, rates, props, state_unknown, tip_partial_lh);
     return set_model_common(e, 1, nullptr, eval, evec, inv_evec, rates, props, state_unknown, tip_partial_lh);
 }
 
 extern "C" int iqhip_set_mixture_model(iqhip_engine *e, int nclass, const int32_t *cat_class, const double *eval,
                                        const double *evec, const double *inv_evec, const double *rates,
                                        const double *props, int state_unknown, const double *tip_partial_lh) {
+    if (e && (e->embed2 || e->n_user == 2) && nclass > 1)
+        return fail(IQHIP_ERR_UNSUPPORTED, "mixture models of binary data are not implemented");
+    if (e && e->embed2 && e->shards.empty())
+        return set_model_binary(e, eval, evec, inv_evec, rates, props, state_unknown, tip_partial_lh);
     return set_model_common(e, nclass, cat_class, eval, evec, inv_evec, rates, props, state_unknown, tip_partial_lh);
 }
 
@@ -1752,6 +1790,12 @@ static int fetch_vec(iqhip_engine *e, const double *dptr, double *out) {
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(tmp.data(), dptr, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
     const int B = e->block;
+    if (e->embed2) {  // the caller's block is 2 doubles per category: components 0, 1 of the embedded vector
+        for (int64_t p = 0; p < e->nptn; p++)
+            for (int c = 0; c < e->ncat; c++)
+                for (int i = 0; i < 2; i++) out[((size_t)p * e->ncat + c) * 2 + i] = tmp[dev_index(e, p, c * 4 + i)];
+        return IQHIP_OK;
+    }
     for (int64_t p = 0; p < e->nptn; p++)
         for (int k = 0; k < B; k++) out[(size_t)p * B + k] = tmp[dev_index(e, p, k)];
     return IQHIP_OK;
@@ -1899,6 +1943,11 @@ extern "C" int iqhip_upload_partial(iqhip_engine *e, uint64_t key, const double 
     if (rc) return rc;
     const int B = e->block;
     std::vector<double> tmp((size_t)e->nptn_pad * B, 0.0);
+    if (e->embed2) {
+        for (int64_t p = 0; p < e->nptn; p++)
+            for (int c = 0; c < e->ncat; c++)
+                for (int i = 0; i < 2; i++) tmp[dev_index(e, p, c * 4 + i)] = partial_lh[((size_t)p * e->ncat + c) * 2 + i];
+    } else
     for (int64_t p = 0; p < e->nptn; p++)
         for (int k = 0; k < B; k++) tmp[dev_index(e, p, k)] = partial_lh[(size_t)p * B + k];
     std::vector<int16_t> sc((size_t)e->nptn_pad, 0);

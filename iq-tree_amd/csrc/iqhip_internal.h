@@ -148,6 +148,13 @@ __host__ __device__ inline void newton_update(NewtonState &s, double pdf, double
 struct iqhip_engine {
     int device = 0;
     int n = 0, ncat = 0, ntaxa = 0;
+    // Binary data (2 states; phylotreesse.cpp:262-276 binds <Vec2d, 2, 2>): embedded EXACTLY into the 4-state kernels --
+    // the eigen-system is padded block-diagonally (U = diag(U2, I2), eigenvalues (l0, l1, 0, 0)), so components 2, 3 of
+    // every vector are identically zero, and a missing character becomes the ambiguity set {0, 1} (DNA code 6 = "A or
+    // C", whose tip vector is the caller's unknown row) instead of the kernels' "unknown = exactly 1.0 in every
+    // component" rule, which would leak into the padding.  n stays 4 internally; the ABI speaks n_user = 2.
+    bool embed2 = false;
+    int n_user = 0;
     int64_t nptn = 0;      // caller-visible patterns
     int64_t nptn_pad = 0;  // padded to the tile size
     int64_t ntiles = 0;    // tiles of `tile` patterns

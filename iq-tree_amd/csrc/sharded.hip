@@ -158,6 +158,7 @@ int set_model(iqhip_engine *p, int nclass, const int32_t *cat_class, const doubl
 
 int set_alignment(iqhip_engine *p, const uint8_t *states, const double *ptn_freq, const double *ptn_invar) {
     if (!p->model_set) return bad(IQHIP_ERR_INVALID, "iqhip_set_alignment: call iqhip_set_model first (needs state_unknown)");
+    // (binary data: p->n is the caller's 2; every shard embeds on its own)
     const size_t N = (size_t)p->nptn;
     std::vector<uint8_t> rows;
     for (size_t g = 0; g < p->shards.size(); g++) {

@@ -44,6 +44,7 @@ enum { ORACLE_SEQ_DNA = 0, ORACLE_SEQ_PROTEIN = 1, ORACLE_SEQ_CODON = 2, ORACLE_
 
 /* (l0+l1)+(l2+l3) with lane k = sum_i a[4i+k]*b[4i+k], unfused; phylokernel.h:427-441 */
 static inline double dot4(const double *a, const double *b, int n) {
+    if (n == 2) return a[0] * b[0] + a[1] * b[1]; /* binary data: <Vec2d, 2, 2> (phylotreesse.cpp:270-274), l0 + l1 */
     double l0 = a[0] * b[0], l1 = a[1] * b[1], l2 = a[2] * b[2], l3 = a[3] * b[3];
     for (int i = 4; i < n; i += 4) {
         l0 = a[i] * b[i] + l0;
@@ -291,11 +292,15 @@ static void branch_val(int n, int ncat, const double *eval, const double *rates,
 
 /* lane-strided running sum over patterns then (l0+l1)+(l2+l3):
  * phylokernel.h:836,954 + vectorclass/vectorf256.h:1652-1657 */
-typedef struct { double l[4]; } lane4;
+/* vector width of the reference instantiation: Vec4d (AVX) for 4 / 20 / 64 states, Vec2d (SSE) for binary data */
+#define VCW(n) ((n) == 2 ? 2 : 4)
+static inline double hsum_l(const double *l, int vc) { return vc == 2 ? l[0] + l[1] : (l[0] + l[1]) + (l[2] + l[3]); }
+typedef struct { double l[4]; int vc; } lane4;
 static inline void lane4_acc(lane4 *s, size_t ptn, double v, double f) {
-    s->l[ptn & 3] = v * f + s->l[ptn & 3];
+    const size_t k = ptn % (size_t)s->vc;
+    s->l[k] = v * f + s->l[k];
 }
-static inline double lane4_sum(const lane4 *s) { return (s->l[0] + s->l[1]) + (s->l[2] + s->l[3]); }
+static inline double lane4_sum(const lane4 *s) { return hsum_l(s->l, s->vc); }
 
 /*
  * a8 / K6, phylokernel.h:733-1020 (no ascertainment-bias patterns).
@@ -312,24 +317,25 @@ double oracle_branch_lnl(int n, int ncat, size_t nptn, const double *eval,
     size_t block = (size_t)n * ncat;
     double *val = (double *)malloc(sizeof(double) * block);
     branch_val(n, ncat, eval, rates, props, len, val);
-    lane4 fin = {{0, 0, 0, 0}};
+    lane4 fin = {{0, 0, 0, 0}, VCW(n)};
+    const int vc = VCW(n);
     for (size_t ptn = 0; ptn < nptn; ptn++) {
         const double *b = node_plh + ptn * block;
         double l[4];
         if (dad_states) {
             const double *t = tip + (size_t)dad_states[ptn] * n * g_nclass;
-            for (int k = 0; k < 4; k++) l[k] = (val[k] * t[TIPIDX(k)]) * b[k];
-            for (size_t i = 4; i < block; i += 4)
-                for (int k = 0; k < 4; k++)
+            for (int k = 0; k < vc; k++) l[k] = (val[k] * t[TIPIDX(k)]) * b[k];
+            for (size_t i = (size_t)vc; i < block; i += (size_t)vc)
+                for (int k = 0; k < vc; k++)
                     l[k] = (val[i + k] * t[TIPIDX(i + k)]) * b[i + k] + l[k];
         } else {
             const double *a = dad_plh + ptn * block;
-            for (int k = 0; k < 4; k++) l[k] = 0.0;
-            for (size_t i = 0; i < block; i += 4)
-                for (int k = 0; k < 4; k++)
+            for (int k = 0; k < vc; k++) l[k] = 0.0;
+            for (size_t i = 0; i < block; i += (size_t)vc)
+                for (int k = 0; k < vc; k++)
                     l[k] = (val[i + k] * b[i + k]) * a[i + k] + l[k];
         }
-        double lh = ((l[0] + l[1]) + (l[2] + l[3])) + ptn_invar[ptn];
+        double lh = hsum_l(l, vc) + ptn_invar[ptn];
         lh = log(fabs(lh));
         pattern_lh[ptn] = lh;
         lane4_acc(&fin, ptn, lh, ptn_freq[ptn]);
@@ -380,23 +386,24 @@ void oracle_derv(int n, int ncat, size_t nptn, const double *eval, const double 
             v1[c * n + i] = cof * val;
             v2[c * n + i] = cof * v1[c * n + i];
         }
-    lane4 sdf = {{0, 0, 0, 0}}, sddf = {{0, 0, 0, 0}};
+    lane4 sdf = {{0, 0, 0, 0}, VCW(n)}, sddf = {{0, 0, 0, 0}, VCW(n)};
+    const int vc = VCW(n);
     for (size_t ptn = 0; ptn < nptn; ptn++) {
         const double *th = theta + ptn * block;
         double p[4], d1[4], d2[4];
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < vc; k++) {
             p[k] = v0[k] * th[k]; d1[k] = v1[k] * th[k]; d2[k] = v2[k] * th[k];
         }
-        for (size_t i = 4; i < block; i += 4)
-            for (int k = 0; k < 4; k++) {
+        for (size_t i = (size_t)vc; i < block; i += (size_t)vc)
+            for (int k = 0; k < vc; k++) {
                 p[k] = th[i + k] * v0[i + k] + p[k];
                 d1[k] = th[i + k] * v1[i + k] + d1[k];
                 d2[k] = th[i + k] * v2[i + k] + d2[k];
             }
-        double lh = ((p[0] + p[1]) + (p[2] + p[3])) + ptn_invar[ptn];
+        double lh = hsum_l(p, vc) + ptn_invar[ptn];
         double inv = 1.0 / fabs(lh);
-        double dfp = ((d1[0] + d1[1]) + (d1[2] + d1[3])) * inv;
-        double ddfp = ((d2[0] + d2[1]) + (d2[2] + d2[3])) * inv;
+        double dfp = hsum_l(d1, vc) * inv;
+        double ddfp = hsum_l(d2, vc) * inv;
         ddfp = ddfp - dfp * dfp;
         lane4_acc(&sdf, ptn, dfp, ptn_freq[ptn]);
         lane4_acc(&sddf, ptn, ddfp, ptn_freq[ptn]);
@@ -419,14 +426,15 @@ double oracle_lnl_from_theta(int n, int ncat, size_t nptn, const double *eval,
             double cof = eval[(size_t)CLS(c) * n + i] * rates[c];
             val[c * n + i] = exp(cof * len) * props[c];
         }
-    lane4 fin = {{0, 0, 0, 0}};
+    lane4 fin = {{0, 0, 0, 0}, VCW(n)};
+    const int vc = VCW(n);
     for (size_t ptn = 0; ptn < nptn; ptn++) {
         const double *th = theta + ptn * block;
         double p[4];
-        for (int k = 0; k < 4; k++) p[k] = val[k] * th[k];
-        for (size_t i = 4; i < block; i += 4)
-            for (int k = 0; k < 4; k++) p[k] = th[i + k] * val[i + k] + p[k];
-        double lh = ((p[0] + p[1]) + (p[2] + p[3])) + ptn_invar[ptn];
+        for (int k = 0; k < vc; k++) p[k] = val[k] * th[k];
+        for (size_t i = (size_t)vc; i < block; i += (size_t)vc)
+            for (int k = 0; k < vc; k++) p[k] = th[i + k] * val[i + k] + p[k];
+        double lh = hsum_l(p, vc) + ptn_invar[ptn];
         lh = log(fabs(lh));
         pattern_lh[ptn] = lh;
         lane4_acc(&fin, ptn, lh, ptn_freq[ptn]);
@@ -460,6 +468,7 @@ double oracle_asc_prob_const_branch(int n, int ncat, size_t n_unobs, const doubl
                                     const double *tip, const uint8_t *dad_states, const double *dad_plh,
                                     const short *dad_scale, const double *node_plh,
                                     const short *node_scale, const double *ptn_invar) {
+    const int vc = VCW(n);
     size_t block = (size_t)n * ncat;
     double *val = (double *)malloc(sizeof(double) * block);
     branch_val(n, ncat, eval, rates, props, len, val);
@@ -470,19 +479,19 @@ double oracle_asc_prob_const_branch(int n, int ncat, size_t n_unobs, const doubl
         int sc = node_scale[ptn];
         if (dad_states) {
             const double *t = tip + (size_t)dad_states[ptn] * n * g_nclass;
-            for (int k = 0; k < 4; k++) l[k] = (val[k] * t[TIPIDX(k)]) * b[k];
-            for (size_t i = 4; i < block; i += 4)
-                for (int k = 0; k < 4; k++) l[k] = (val[i + k] * t[TIPIDX(i + k)]) * b[i + k] + l[k];
+            for (int k = 0; k < vc; k++) l[k] = (val[k] * t[TIPIDX(k)]) * b[k];
+            for (size_t i = (size_t)vc; i < block; i += (size_t)vc)
+                for (int k = 0; k < vc; k++) l[k] = (val[i + k] * t[TIPIDX(i + k)]) * b[i + k] + l[k];
         } else {
             const double *a = dad_plh + ptn * block;
             sc += dad_scale[ptn];
-            for (int k = 0; k < 4; k++) l[k] = 0.0;
-            for (size_t i = 0; i < block; i += 4)
-                for (int k = 0; k < 4; k++) l[k] = (val[i + k] * b[i + k]) * a[i + k] + l[k];
+            for (int k = 0; k < vc; k++) l[k] = 0.0;
+            for (size_t i = 0; i < block; i += (size_t)vc)
+                for (int k = 0; k < vc; k++) l[k] = (val[i + k] * b[i + k]) * a[i + k] + l[k];
         }
         if (sc >= 1)
-            for (int k = 0; k < 4; k++) l[k] *= SCALING_THRESHOLD;
-        prob_const += ((l[0] + l[1]) + (l[2] + l[3])) + ptn_invar[ptn];
+            for (int k = 0; k < vc; k++) l[k] *= SCALING_THRESHOLD;
+        prob_const += hsum_l(l, vc) + ptn_invar[ptn];
     }
     free(val);
     return prob_const;
@@ -495,6 +504,7 @@ void oracle_asc_theta_sums(int n, int ncat, size_t n_unobs, const double *eval, 
                            const double *props, double len, const double *theta,
                            const short *sum_scale /* NULL: no rescale (Derv) */,
                            const double *ptn_invar, double *out) {
+    const int vc = VCW(n);
     size_t block = (size_t)n * ncat;
     double *v0 = (double *)malloc(sizeof(double) * block * 3);
     double *v1 = v0 + block, *v2 = v1 + block;
@@ -510,18 +520,18 @@ void oracle_asc_theta_sums(int n, int ncat, size_t n_unobs, const double *eval, 
     for (size_t ptn = 0; ptn < n_unobs; ptn++) {
         const double *th = theta + ptn * block;
         double p[4], d1[4], d2[4];
-        for (int k = 0; k < 4; k++) { p[k] = v0[k] * th[k]; d1[k] = v1[k] * th[k]; d2[k] = v2[k] * th[k]; }
-        for (size_t i = 4; i < block; i += 4)
-            for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < vc; k++) { p[k] = v0[k] * th[k]; d1[k] = v1[k] * th[k]; d2[k] = v2[k] * th[k]; }
+        for (size_t i = (size_t)vc; i < block; i += (size_t)vc)
+            for (int k = 0; k < vc; k++) {
                 p[k] = th[i + k] * v0[i + k] + p[k];
                 d1[k] = th[i + k] * v1[i + k] + d1[k];
                 d2[k] = th[i + k] * v2[i + k] + d2[k];
             }
         if (sum_scale && sum_scale[ptn] >= 1)
-            for (int k = 0; k < 4; k++) p[k] *= SCALING_THRESHOLD;
-        out[0] += ((p[0] + p[1]) + (p[2] + p[3])) + ptn_invar[ptn];
-        out[1] += (d1[0] + d1[1]) + (d1[2] + d1[3]);
-        out[2] += (d2[0] + d2[1]) + (d2[2] + d2[3]);
+            for (int k = 0; k < vc; k++) p[k] *= SCALING_THRESHOLD;
+        out[0] += hsum_l(p, vc) + ptn_invar[ptn];
+        out[1] += hsum_l(d1, vc);
+        out[2] += hsum_l(d2, vc);
     }
     free(v0);
 }

@@ -61,7 +61,7 @@ def test_unsupported_shapes_are_rejected(pkg):
     lib = pkg.libiqhip()
     e = C.c_void_p()
     assert lib.iqhip_create(C.byref(e), 0, 5, 4, 100, 5) == 3   # nstates 5: UNSUPPORTED (reference: scalar kernel)
-    assert lib.iqhip_create(C.byref(e), 0, 2, 4, 100, 5) == 3   # binary data: not in scope
+    assert lib.iqhip_create(C.byref(e), 0, 3, 4, 100, 5) == 3   # (2 = binary data is supported: tests/test_binary_gpu.py)
     assert lib.iqhip_create(C.byref(e), 0, 4, 4, 0, 5) == 2     # nptn 0: INVALID
     # a 4-state vector of 4 GiB or more would wrap the kernels' 32-bit per-lane offsets: refused, not corrupted
     assert lib.iqhip_create(C.byref(e), 0, 4, 4, (1 << 32) // (16 * 8), 5) == 3

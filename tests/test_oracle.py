@@ -21,7 +21,7 @@ def _setup(synth, oracle, ntaxa, nsites, n, ncat, seed, seq_type, missing=0.0, p
     return model, nwk, pat, freq, invar, tree, su
 
 
-@pytest.mark.parametrize("n,ncat,seq_type", [(4, 4, 0), (4, 1, 0), (20, 4, 1), (64, 1, 2)])
+@pytest.mark.parametrize("n,ncat,seq_type", [(4, 4, 0), (4, 1, 0), (20, 4, 1), (64, 1, 2), (2, 4, 3), (2, 1, 3)])
 def test_oracle_matches_textbook(synth, oracle, n, ncat, seq_type):
     import textbook
     model, nwk, pat, freq, invar, tree, su = _setup(synth, oracle, 9, 60, n, ncat, 11 + n, seq_type, missing=0.1)
@@ -86,8 +86,9 @@ def test_oracle_scaling_counters(synth, oracle):
     assert abs(lnl - float((site * freq).sum())) <= 1e-9 * abs(lnl)
 
 
-def test_oracle_derivatives_match_finite_differences(synth, oracle):
-    model, nwk, pat, freq, invar, tree, su = _setup(synth, oracle, 9, 120, 4, 4, 21, 0)
+@pytest.mark.parametrize("n,seq_type", [(4, 0), (2, 3)])
+def test_oracle_derivatives_match_finite_differences(synth, oracle, n, seq_type):
+    model, nwk, pat, freq, invar, tree, su = _setup(synth, oracle, 9, 120, n, 4, 21, seq_type)
     for (a, b) in [(0, tree.adj[0][0][0]), (tree.ntaxa, tree.adj[tree.ntaxa][0][0])]:
         t = tree.length(a, b)
         th, sf = tree.theta(a, b)
