@@ -46,12 +46,15 @@ bool PhyloTree::hipKernelUsable() {
     if (!aln || !model_factory || !model || !site_rate) return false;
     if (model->isSiteSpecificModel() || !model->isReversible()) return false;
     int n = aln->num_states;
-    // mixtures (ModelMixture, incl. fused mixture-rate models): 20 states, <= 96 (class, rate) components
+    // mixtures (ModelMixture, incl. fused mixture-rate models): <= 96 (class, rate) components for 20 states, <= 16
+    // for 64, <= 8 for 4; none for binary data
     if (model->isMixture()) {
         int ncomp = model_factory->fused_mix_rate ? site_rate->getNRate() : site_rate->getNRate() * model->getNMixtures();
-        if (n != 20 || ncomp > 96) return false;
+        int limit = n == 20 ? 96 : n == 64 ? 16 : n == 4 ? 8 : 0;
+        if (ncomp > limit) return false;
     }
-    return (n == 4 || n == 20 || n == 64) && iqhip_device_count() > 0;
+    // the reference's SIMD dispatch cases (phylotreesse.cpp:262-357): binary, DNA, protein, codon
+    return (n == 2 || n == 4 || n == 20 || n == 64) && iqhip_device_count() > 0;
 }
 
 void PhyloTree::setLikelihoodKernelHIP() {
