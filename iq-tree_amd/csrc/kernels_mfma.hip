@@ -34,12 +34,102 @@ namespace iqhip {
 // child load / result store is a FLAT instruction, which also counts in lgkmcnt and so is drained by
 // every wait on an LDS read.
 #define CONST_AS __attribute__((address_space(4)))
+// LDS reads spelled with their address space: a generic pointer lets the optimiser merge "tip value from LDS" and
+// "previous result from a register array" into ONE flat load through a selected address, which parks the array in
+// scratch and -- flat loads return out of order -- turns the wait into s_waitcnt vmcnt(0), i.e. a drain of every
+// outstanding store and prefetch once per category step (measured r02: the 20-state kernel's whole stall)
+#define LDS_AS __attribute__((address_space(3)))
+template <typename T>
+__device__ __forceinline__ const LDS_AS T *as_lds(const T *p) {
+    return (const LDS_AS T *)p;
+}
+
+// ---------------------------------------------------------------------------------------
+// IQHIP_WAVE_TRACE (timing-study build, tools/build_alt.sh trace -DIQHIP_WAVE_TRACE; never defined in the shipped
+// library): every wave of a traversal kernel records its begin/end (constant 100 MHz clock + shader clock) and the SIMD
+// it ran on; a few waves also stamp the shader clock at the phases of every (op, category) step.  The host appends the
+// records of selected launches to $IQHIP_TRACE_FILE (tools/wave_trace.py reads it).
+// ---------------------------------------------------------------------------------------
+#ifdef IQHIP_WAVE_TRACE
+struct WaveRec { unsigned long long rt0, rt1, ct0, ct1; unsigned hw, xcc, vblock, wave, nstamp, det, kind, pad; };
+#define TRACE_MAXW (1 << 15)
+#define TRACE_NDET 48
+#define TRACE_MAXSTAMP 2048
+__device__ WaveRec g_wrec[TRACE_MAXW];
+__device__ unsigned g_wrec_n;
+__device__ unsigned long long g_stamps[TRACE_NDET][TRACE_MAXSTAMP];
+__device__ unsigned g_det_n;
+struct WaveTracer {
+    unsigned long long rt0, ct0;
+    int det;
+    unsigned n, vblock, wave, kind;
+    __device__ __forceinline__ void begin(int vb, int w, int k) {
+        vblock = vb; wave = w; kind = k; n = 0; det = -1;
+        if ((vb % 37) == 0 && w == (vb / 37) % 4) {
+            unsigned d = 0;
+            if ((threadIdx.x & 63) == 0) d = atomicAdd(&g_det_n, 1u);
+            d = __builtin_amdgcn_readfirstlane(d);
+            if (d < TRACE_NDET) det = (int)d;
+        }
+        rt0 = __builtin_amdgcn_s_memrealtime();
+        ct0 = __builtin_amdgcn_s_memtime();
+    }
+    __device__ __forceinline__ void stamp() {
+        __builtin_amdgcn_sched_barrier(0);
+        if (det >= 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if ((threadIdx.x & 63) == 0 && n < TRACE_MAXSTAMP) g_stamps[det][n] = t;
+            n++;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void end() {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime(), ct1 = __builtin_amdgcn_s_memtime();
+        if ((threadIdx.x & 63) == 0) {
+            const unsigned slot = atomicAdd(&g_wrec_n, 1u);
+            if (slot < TRACE_MAXW) {
+                WaveRec r;
+                r.rt0 = rt0; r.rt1 = rt1; r.ct0 = ct0; r.ct1 = ct1;
+                r.hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+                r.xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+                r.vblock = vblock; r.wave = wave; r.nstamp = n; r.det = (unsigned)det; r.kind = kind; r.pad = 0;
+                g_wrec[slot] = r;
+            }
+        }
+    }
+};
+#define TRACE_DECL WaveTracer wtr
+#define TRACE_BEGIN(vb, w, k) wtr.begin(vb, w, k)
+#define TRACE_STAMP() wtr.stamp()
+#define TRACE_END() wtr.end()
+#else
+#define TRACE_DECL
+#define TRACE_BEGIN(vb, w, k)
+#define TRACE_STAMP()
+#define TRACE_END()
+#endif
 template <typename T>
 __device__ __forceinline__ const CONST_AS T *as_const(const T *p) {
     return (const CONST_AS T *)(p);
 }
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// maximum over the four lane groups of a pattern (lanes p, p+16, p+32, p+48) on the VALU: gfx950's permlane swaps
+// exchange half-waves / odd-even rows of two registers, so swap(x, x) hands every lane its partner's value without
+// the LDS round trips of ds_bpermute (the per-op scaling test used to cost two of them, exposed, per op)
+__device__ __forceinline__ double group_max(double v) {
+    unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = fmax(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+    lo = __double2loint(v);
+    hi = __double2hiint(v);
+    auto c = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto d = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return fmax(__hiloint2double(d[0], c[0]), __hiloint2double(d[1], c[1]));
+}
 
 __device__ __forceinline__ double wave_sum_m(double v) {
 #pragma unroll
@@ -208,8 +298,7 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
                     }
             }
             // column (pattern) max over the 4 lane groups
-            lmax = fmax(lmax, __shfl_xor(lmax, 16, 64));
-            lmax = fmax(lmax, __shfl_xor(lmax, 32, 64));
+            lmax = group_max(lmax);
             const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0) && !op.no_scale;
             double my_scale = 0.0;
             if (__any(do_scale)) {
@@ -220,7 +309,7 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
                 }
             }
             if (g == 0) op.dst_sc[ptn] = (int16_t)sc;
-            const double ws = wave_sum_m(my_scale);
+            const double ws = __any(my_scale != 0.0) ? wave_sum_m(my_scale) : 0.0;  // (no rescaling in this op: nothing to add)
             if (lane == 0) {
                 A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
                 if (ws != 0.0) __hip_atomic_fetch_or(&A.fold_flags[2 + op.out_row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -389,6 +478,8 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
     const double invar = A.invar[ptn];
     const CONST_AS DevOp *ops = as_const(A.ops);
     const int S = A.state_unknown;                // rows of a leaf table
+    TRACE_DECL;
+    TRACE_BEGIN(vblock, wave, N);
 
     // AREG (20 states): the A fragments of U and U^-1 (16-row tile + 4-row tail: 4 x 5 doubles) stay in registers for
     // the whole launch; with them in LDS every k-step of every chain waited for an LDS round trip before its MFMAs
@@ -422,7 +513,8 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
 #pragma unroll
         for (int s = 0; s < KS; s++) PFn[s] = src[s * 64 + lane];
         if (g == 0) pfn_sc = f.pf_sc[(f.real_mask & 1) ? ptn : (int64_t)p];
-        if (TAB) { sLn = f.sl[ptn]; sRn = f.sr[ptn]; }
+        sLn = f.sl[ptn];
+        sRn = f.sr[ptn];
     }
     v4f64 nL[MTF], nR[MTF];   // TABPF: table rows of the coming step
     double nL4 = 0.0, nR4 = 0.0;
@@ -452,20 +544,22 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
         if (!active) { k += kn; continue; }
 
         for (int kk = 0; kk < kn; kk++, k++) {
+            TRACE_STAMP();   // op start
             const CONST_AS DevOp &op = ops[k];
             const CONST_AS DevOp &nxop = ops[k + 1];
             const bool leafL = op.left_kind == CHILD_LEAF, leafR = op.right_kind == CHILD_LEAF;
             const double *exL = sReg + op.lds_left, *exR = sReg + op.lds_right;
-            int sc = 0, sL = 0, sR = 0;
-            if (TAB) {
-                sL = sLn; sR = sRn;
-                sLn = nxop.sl[ptn];   // (dummy rows for non-leaf children and the sentinel)
-                sRn = nxop.sr[ptn];
-                if (!leafL) sc += pfn_sc;
-            } else {
-                if (leafL) sL = op.sl[ptn]; else sc += pfn_sc;          // pfn_sc: valid on g == 0 lanes
-                if (leafR) sR = op.sr[ptn];
-            }
+            // leaf states are requested one op ahead (sl / sr of non-leaf children and of the sentinel point at valid
+            // dummy rows): fetched at the op itself, the first products of every leaf op waited out an L2 round trip
+            int sc = 0;
+            const int sL = sLn, sR = sRn;
+            sLn = nxop.sl[ptn];
+            sRn = nxop.sr[ptn];
+            if (!leafL) sc += pfn_sc;                                   // pfn_sc: valid on g == 0 lanes
+            // scalar fields of the op that are needed only in its tail: requested now
+            int16_t *const dst_sc = op.dst_sc;
+            const int out_row = op.out_row;
+            const bool no_scale = op.no_scale;
             if (op.right_kind == CHILD_LOAD) {
                 // rare (PF, LOAD): read the right child now into the `prev` registers
                 const double *src = op.ld + tbase;
@@ -483,9 +577,9 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
             const bool anyUnk = __any(unkL || unkR);
             // tip_partial_lh row of this lane's pattern state (phylotreesse.cpp:464-527)
             auto tip_at = [&](int st, int i) -> double {
-                if (st >= N) return sTipx[(st - N) * N + i];
-                if (TIP_COPY) return sUiT[st * N + i];
-                return sUi[aidx<KS>(i >> 4, st >> 2, (st & 3) * 16 + (i & 15))];  // U^-1[i][st] in the A image
+                if (st >= N) return as_lds(sTipx)[(st - N) * N + i];
+                if (TIP_COPY) return as_lds(sUiT)[st * N + i];
+                return as_lds(sUi)[aidx<KS>(i >> 4, st >> 2, (st & 3) * 16 + (i & 15))];  // U^-1[i][st] in the A image
             };
             // TAB: this lane's slice of the leaf children's table rows (4 contiguous doubles per M-tile)
             const double *rowL = op.tabL + (size_t)(sL < S ? sL : 0) * N + 4 * g;
@@ -497,7 +591,11 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
                 // streamed child of the next step: (k, c+1) or (k+1, 0); its k-step slices replace the
                 // PFn registers one by one, right after this step has consumed them
                 const CONST_AS DevOp &nd = (c + 1 < C) ? op : nxop;
+#ifdef IQHIP_MFMA_ABLATE_NOLOAD  // timing-only build switch; never defined in the shipped library
+                const bool nreal = false;
+#else
                 const bool nreal = nd.real_mask & 1;
+#endif
                 const double *nsrc = nd.pf + (nreal ? tbase + (size_t)(coff + ((c + 1 < C) ? c + 1 : 0)) * N * 16 : 0);
                 // N = 20 (5 k-steps): cheaper to copy the operands out and issue the whole prefetch up
                 // front; N = 64 (16 k-steps): stream it, the copies would not fit the register file.
@@ -666,6 +764,7 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
                     hadamard(YL, yl4, unkR, false);
                 }
                 if (c + 1 == C && g == 0) pfn_sc = nd.pf_sc[nreal ? ptn : (int64_t)p];
+                TRACE_STAMP();   // products + Hadamard done
                 v4f64 O[MTF];
                 double o4 = 0.0;
 #pragma unroll
@@ -698,9 +797,9 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
 #endif
                     lmax = fmax(lmax, fabs(o4));
                 }
+                TRACE_STAMP();   // contraction done, stores issued
             }
-            lmax = fmax(lmax, __shfl_xor(lmax, 16, 64));
-            lmax = fmax(lmax, __shfl_xor(lmax, 32, 64));
+            lmax = group_max(lmax);
             if constexpr (CS > 1) {  // maximum over the categories held by the other waves of this tile
                 __shared__ double s_lmax[2][WG / 64][16];
                 const int par = k & 1;
@@ -710,7 +809,11 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
 #pragma unroll
                 for (int q = 0; q < CS; q++) lmax = fmax(lmax, s_lmax[par][w0 + q][p]);
             }
-            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0) && !op.no_scale;
+#if defined(IQHIP_MFMA_ABLATE_NOLOAD) || defined(IQHIP_MFMA_ABLATE_NOSTORE)
+            const bool do_scale = lmax == -1.0;  // (garbage inputs must not take the rescaling path in a timing build)
+#else
+            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0) && !no_scale;
+#endif
             double my_scale = 0.0;
             if (__any(do_scale)) {
                 if (do_scale) {
@@ -733,14 +836,15 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
                 }
             }
             prev_sc = sc;
-            if (lead && g == 0) op.dst_sc[ptn] = (int16_t)sc;
-            const double ws = wave_sum_m(my_scale);
+            if (lead && g == 0) dst_sc[ptn] = (int16_t)sc;
+            const double ws = __any(my_scale != 0.0) ? wave_sum_m(my_scale) : 0.0;  // (no rescaling in this op: nothing to add)
             if (lead && lane == 0) {
-                A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
-                if (ws != 0.0) __hip_atomic_fetch_or(&A.fold_flags[2 + op.out_row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                A.slab[(size_t)(2 + out_row) * A.nwaves + (int)tl] = ws;
+                if (ws != 0.0) __hip_atomic_fetch_or(&A.fold_flags[2 + out_row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
+    TRACE_END();
 }
 
 template <int N, int C, int WG, int CS = 1, bool TAB = false>
@@ -888,8 +992,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_mix20(const TravMArgs A
                 dst[(size_t)(c * N + 16 + g) * 16 + p] = o4;
                 lmax = fmax(lmax, fabs(o4));
             }
-            lmax = fmax(lmax, __shfl_xor(lmax, 16, 64));
-            lmax = fmax(lmax, __shfl_xor(lmax, 32, 64));
+            lmax = group_max(lmax);
             if constexpr (CS > 1) {
                 __shared__ double s_lmax[2][WG / 64][16];
                 const int par = k & 1;
@@ -909,7 +1012,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_mix20(const TravMArgs A
                 }
             }
             if (lead && g == 0) op.dst_sc[ptn] = (int16_t)sc;
-            const double ws = wave_sum_m(my_scale);
+            const double ws = __any(my_scale != 0.0) ? wave_sum_m(my_scale) : 0.0;  // (no rescaling in this op: nothing to add)
             if (lead && lane == 0) {
                 A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
                 if (ws != 0.0) __hip_atomic_fetch_or(&A.fold_flags[2 + op.out_row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -978,6 +1081,8 @@ __device__ __forceinline__ void trav_rows64_body(const TravMArgs &A, const int v
     const double invar = A.invar[ptn];
     const CONST_AS DevOp *ops = as_const(A.ops);
     const bool lead = wave == 0;
+    TRACE_DECL;
+    TRACE_BEGIN(vblock, wave, 1064);
 
     // A fragments of this wave's 16 rows: lane (row = 16*wave + (lane & 15), k = 4s + (lane >> 4))
     double aU[KS], aUi[KS];
@@ -1081,8 +1186,7 @@ __device__ __forceinline__ void trav_rows64_body(const TravMArgs &A, const int v
                 lmax = fmax(lmax, fabs(O[r]));
             }
             prev = O;
-            lmax = fmax(lmax, __shfl_xor(lmax, 16, 64));
-            lmax = fmax(lmax, __shfl_xor(lmax, 32, 64));
+            lmax = group_max(lmax);
             if (g == 0) s_lmax[par][wave][p] = lmax;
             __syncthreads();
             lmax = fmax(fmax(s_lmax[par][0][p], s_lmax[par][1][p]), fmax(s_lmax[par][2][p], s_lmax[par][3][p]));
@@ -1101,13 +1205,14 @@ __device__ __forceinline__ void trav_rows64_body(const TravMArgs &A, const int v
             }
             prev_sc = sc;
             if (lead && g == 0) op.dst_sc[ptn] = (int16_t)sc;
-            const double ws = wave_sum_m(my_scale);
+            const double ws = __any(my_scale != 0.0) ? wave_sum_m(my_scale) : 0.0;  // (no rescaling in this op: nothing to add)
             if (lead && lane == 0) {
                 A.slab[(size_t)(2 + op.out_row) * A.nwaves + (int)tl] = ws;
                 if (ws != 0.0) __hip_atomic_fetch_or(&A.fold_flags[2 + op.out_row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
+    TRACE_END();
 }
 
 template <int WG, bool TAB>
@@ -1192,7 +1297,55 @@ static hipError_t launch_trav_top64(iqhip_engine *e, TravMArgs &A, int nfull) {
     return hipGetLastError();
 }
 
+#ifdef IQHIP_WAVE_TRACE
+static hipError_t launch_traverse_mfma_impl(iqhip_engine *e, const int *seg_table, int nsegs, int nwaves, bool top_stage);
+// timing-study build: drain the stream after every traversal launch and append the wave records of launches
+// [IQHIP_TRACE_FIRST, IQHIP_TRACE_FIRST + IQHIP_TRACE_COUNT) to $IQHIP_TRACE_FILE
 hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs, int nwaves, bool top_stage) {
+    static int launch_no = 0;
+    static const int first = getenv("IQHIP_TRACE_FIRST") ? atoi(getenv("IQHIP_TRACE_FIRST")) : 40;
+    static const int count = getenv("IQHIP_TRACE_COUNT") ? atoi(getenv("IQHIP_TRACE_COUNT")) : 4;
+    const unsigned zero = 0;
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_wrec_n), &zero, sizeof(zero), 0, hipMemcpyHostToDevice, e->stream);
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_det_n), &zero, sizeof(zero), 0, hipMemcpyHostToDevice, e->stream);
+    hipError_t rc = launch_traverse_mfma_impl(e, seg_table, nsegs, nwaves, top_stage);
+    if (rc != hipSuccess) return rc;
+    rc = hipStreamSynchronize(e->stream);
+    if (rc != hipSuccess) return rc;
+    const int no = launch_no++;
+    const char *path = getenv("IQHIP_TRACE_FILE");
+    if (path && no >= first && no < first + count) {
+        unsigned nw = 0, nd = 0;
+        (void)hipMemcpyFromSymbol(&nw, HIP_SYMBOL(g_wrec_n), sizeof(nw));
+        (void)hipMemcpyFromSymbol(&nd, HIP_SYMBOL(g_det_n), sizeof(nd));
+        nw = nw < TRACE_MAXW ? nw : TRACE_MAXW;
+        nd = nd < TRACE_NDET ? nd : TRACE_NDET;
+        std::vector<WaveRec> recs(nw);
+        if (nw) (void)hipMemcpyFromSymbol(recs.data(), HIP_SYMBOL(g_wrec), sizeof(WaveRec) * nw);
+        std::vector<unsigned long long> st((size_t)TRACE_NDET * TRACE_MAXSTAMP);
+        (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * st.size());
+        FILE *f = fopen(path, "a");
+        if (f) {
+            fprintf(f, "L %d top %d nsegs %d nwaves %d n %d ncat %d\n", no, (int)top_stage, nsegs, nwaves, e->n, e->ncat);
+            for (const WaveRec &r : recs) {
+                fprintf(f, "W %u %u %u %u %u %llu %llu %llu %llu %d %u\n", r.kind, r.vblock, r.wave, r.xcc, r.hw, r.rt0, r.rt1, r.ct0,
+                        r.ct1, (int)r.det, r.nstamp);
+                if ((int)r.det >= 0 && r.det < nd) {
+                    fprintf(f, "S %u", r.det);
+                    const unsigned ns = r.nstamp < TRACE_MAXSTAMP ? r.nstamp : TRACE_MAXSTAMP;
+                    for (unsigned i = 0; i < ns; i++) fprintf(f, " %llu", st[(size_t)r.det * TRACE_MAXSTAMP + i] - r.ct0);
+                    fprintf(f, "\n");
+                }
+            }
+            fclose(f);
+        }
+    }
+    return hipSuccess;
+}
+static hipError_t launch_traverse_mfma_impl(iqhip_engine *e, const int *seg_table, int nsegs, int nwaves, bool top_stage) {
+#else
+hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs, int nwaves, bool top_stage) {
+#endif
     TravMArgs A;
     A.ops = e->d_ops;
     A.evec = e->d_evec;
