@@ -131,6 +131,22 @@ __device__ __forceinline__ double group_max(double v) {
     return fmax(__hiloint2double(d[0], c[0]), __hiloint2double(d[1], c[1]));
 }
 
+// The scaling test max|x| < 2^-256 on the 32-bit vector ALU: for finite doubles |x| < 2^-256 <=> the high word of |x|
+// is below that of 2^-256 (whose low word is 0), and the high words order like the values.  fp64 vector instructions
+// run on the unit that executes the fp64 matrix instructions and ADD to their time (3.1 ns each against 29.5 ns for a
+// 16x16x4, tools/mfma_issue_probe.hip), 32-bit ones overlap with them: v_and + v_max_u32 replace two v_max_f64 per value.
+constexpr unsigned kScalingThresholdHi = 0x2FF00000u;   // high word of 0x1p-256
+__device__ __forceinline__ unsigned amax_hi(unsigned m, double v) {
+    const unsigned h = (unsigned)__double2hiint(v) & 0x7fffffffu;
+    return m > h ? m : h;
+}
+__device__ __forceinline__ unsigned group_max_u(unsigned v) {
+    auto a = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    v = a[0] > a[1] ? a[0] : a[1];
+    auto b = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return b[0] > b[1] ? b[0] : b[1];
+}
+
 __device__ __forceinline__ double wave_sum_m(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -229,7 +245,7 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
             const bool unkL = leafL && sL == A.state_unknown, unkR = leafR && sR == A.state_unknown;
             const double *vL = op.pf + tbase, *vR = op.ld + tbase;
             double *dst = op.dst + tbase;
-            double lmax = 0.0;
+            unsigned lmax = 0;
             for (int c = 0; c < C; c++) {
                 // A operands of this category's class
                 const double *aU = sU, *aUi = sUi;
@@ -293,13 +309,13 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
                         const int row = 16 * m + 4 * r + g;
                         if (16 * m + 4 * r < N) {  // whole 4-row group valid (N is a multiple of 4)
                             dst[(size_t)(c * N + row) * 16 + p] = O[m][r];
-                            lmax = fmax(lmax, fabs(O[m][r]));
+                            lmax = amax_hi(lmax, O[m][r]);
                         }
                     }
             }
             // column (pattern) max over the 4 lane groups
-            lmax = group_max(lmax);
-            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0) && !op.no_scale;
+            lmax = group_max_u(lmax);
+            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThresholdHi) && (invar == 0.0) && !op.no_scale;
             double my_scale = 0.0;
             if (__any(do_scale)) {
                 if (do_scale) {
@@ -585,7 +601,7 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
             const double *rowL = op.tabL + (size_t)(sL < S ? sL : 0) * N + 4 * g;
             const double *rowR = op.tabR + (size_t)(sR < S ? sR : 0) * N + 4 * g;
             double *dst = op.dst + tbase;
-            double lmax = 0.0;
+            unsigned lmax = 0;
 #pragma unroll
             for (int c = 0; c < C; c++) {
                 // streamed child of the next step: (k, c+1) or (k+1, 0); its k-step slices replace the
@@ -787,7 +803,7 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
 #ifndef IQHIP_MFMA_ABLATE_NOSTORE  // timing-only build switch; never defined in the shipped library
                         dst[(size_t)((coff + c) * N + row) * 16 + p] = O[m][r];
 #endif
-                        lmax = fmax(lmax, fabs(O[m][r]));
+                        lmax = amax_hi(lmax, O[m][r]);
                     }
                 }
                 if (TAIL4) {
@@ -795,24 +811,24 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
 #ifndef IQHIP_MFMA_ABLATE_NOSTORE
                     dst[(size_t)((coff + c) * N + 16 * MTF + g) * 16 + p] = o4;
 #endif
-                    lmax = fmax(lmax, fabs(o4));
+                    lmax = amax_hi(lmax, o4);
                 }
                 TRACE_STAMP();   // contraction done, stores issued
             }
-            lmax = group_max(lmax);
+            lmax = group_max_u(lmax);
             if constexpr (CS > 1) {  // maximum over the categories held by the other waves of this tile
-                __shared__ double s_lmax[2][WG / 64][16];
+                __shared__ unsigned s_lmax[2][WG / 64][16];
                 const int par = k & 1;
                 if (g == 0) s_lmax[par][wave][p] = lmax;
                 __syncthreads();
                 const int w0 = (wave / CS) * CS;
 #pragma unroll
-                for (int q = 0; q < CS; q++) lmax = fmax(lmax, s_lmax[par][w0 + q][p]);
+                for (int q = 0; q < CS; q++) lmax = max(lmax, s_lmax[par][w0 + q][p]);
             }
 #if defined(IQHIP_MFMA_ABLATE_NOLOAD) || defined(IQHIP_MFMA_ABLATE_NOSTORE)
-            const bool do_scale = lmax == -1.0;  // (garbage inputs must not take the rescaling path in a timing build)
+            const bool do_scale = lmax == 0xffffffffu;  // (garbage inputs must not take the rescaling path in a timing build)
 #else
-            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0) && !no_scale;
+            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThresholdHi) && (invar == 0.0) && !no_scale;
 #endif
             double my_scale = 0.0;
             if (__any(do_scale)) {
@@ -933,7 +949,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_mix20(const TravMArgs A
             const int strideL = leafL ? N : N * 16, stepL = leafL ? 4 : 64;  // per component / per k-step
             const int strideR = leafR ? N : N * 16, stepR = leafR ? 4 : 64;
             double *dst = op.dst + tbase;
-            double lmax = 0.0;
+            unsigned lmax = 0;
             double nl[KS], nr[KS];
 #pragma unroll
             for (int s = 0; s < KS; s++) { nl[s] = srcL[(size_t)c_lo * strideL + s * stepL]; nr[s] = srcR[(size_t)c_lo * strideR + s * stepR]; }
@@ -987,22 +1003,22 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_mix20(const TravMArgs A
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     dst[(size_t)(c * N + 4 * r + g) * 16 + p] = O[r];
-                    lmax = fmax(lmax, fabs(O[r]));
+                    lmax = amax_hi(lmax, O[r]);
                 }
                 dst[(size_t)(c * N + 16 + g) * 16 + p] = o4;
-                lmax = fmax(lmax, fabs(o4));
+                lmax = amax_hi(lmax, o4);
             }
-            lmax = group_max(lmax);
+            lmax = group_max_u(lmax);
             if constexpr (CS > 1) {
-                __shared__ double s_lmax[2][WG / 64][16];
+                __shared__ unsigned s_lmax[2][WG / 64][16];
                 const int par = k & 1;
                 if (g == 0) s_lmax[par][wave][p] = lmax;
                 __syncthreads();
                 const int w0 = (wave / CS) * CS;
 #pragma unroll
-                for (int q = 0; q < CS; q++) lmax = fmax(lmax, s_lmax[par][w0 + q][p]);
+                for (int q = 0; q < CS; q++) lmax = max(lmax, s_lmax[par][w0 + q][p]);
             }
-            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0) && !op.no_scale;
+            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThresholdHi) && (invar == 0.0) && !op.no_scale;
             double my_scale = 0.0;
             if (__any(do_scale)) {
                 if (do_scale) {
@@ -1064,7 +1080,7 @@ __device__ __forceinline__ void trav_rows64_body(const TravMArgs &A, const int v
     double *sX = sTip + (N + nx) * N;          // [2 parities][KS][64] previous result as k-step slices
     double *sT = sX + 2 * KS * 64;             // [2 parities][KS][64] Hadamard product
     double *sReg = sT + 2 * KS * 64;           // per (op, child) exponentials [N] of the chunk
-    __shared__ double s_lmax[2][4][16];
+    __shared__ unsigned s_lmax[2][4][16];
     for (int t = threadIdx.x; t < (N + nx) * N; t += WG) sTip[t] = A.tip[t];
 
     const int lane = threadIdx.x & 63;
@@ -1179,18 +1195,18 @@ __device__ __forceinline__ void trav_rows64_body(const TravMArgs &A, const int v
 #pragma unroll
             for (int s = 0; s < KS; s++) O = __builtin_amdgcn_mfma_f64_16x16x4f64(aUi[s], tb[s * 64 + lane], O, 0, 0, 0);
             double *dst = op.dst + tbase;
-            double lmax = 0.0;
+            unsigned lmax = 0;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 dst[(size_t)(16 * wave + 4 * r + g) * 16 + p] = O[r];
-                lmax = fmax(lmax, fabs(O[r]));
+                lmax = amax_hi(lmax, O[r]);
             }
             prev = O;
-            lmax = group_max(lmax);
+            lmax = group_max_u(lmax);
             if (g == 0) s_lmax[par][wave][p] = lmax;
             __syncthreads();
-            lmax = fmax(fmax(s_lmax[par][0][p], s_lmax[par][1][p]), fmax(s_lmax[par][2][p], s_lmax[par][3][p]));
-            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThreshold) && (invar == 0.0) && !op.no_scale;
+            lmax = max(max(s_lmax[par][0][p], s_lmax[par][1][p]), max(s_lmax[par][2][p], s_lmax[par][3][p]));
+            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThresholdHi) && (invar == 0.0) && !op.no_scale;
             double my_scale = 0.0;
             if (__any(do_scale)) {
                 if (do_scale) {
