@@ -433,7 +433,12 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
     const size_t nst = (size_t)state_unknown + 1;
     const size_t o_eval = 0, o_evec = o_eval + n, o_ievec = o_evec + (size_t)n * n, o_rates = o_ievec + (size_t)n * n,
                  o_props = o_rates + C, o_tip = o_props + C, o_evalc = o_tip + nst * n, o_tipc = o_evalc + (size_t)C * n,
-                 o_cls = o_tipc + nst * C * n, total = o_cls + ((size_t)C + 1) / 2;
+                 o_cls = o_tipc + nst * C * n;
+    const int a_mt = n / 16, a_ks = n / 4;
+    const bool a_tail = (n % 16) == 4;
+    const size_t aimg_doubles = (n == 20 || n == 64) ? (size_t)2 * a_mt * a_ks * 64 + (a_tail ? (size_t)2 * a_ks * 64 : 0) : 0;
+    const size_t o_aimg = (o_cls + ((size_t)C + 1) / 2 + 1) / 2 * 2;   // 16-byte aligned
+    const size_t total = o_aimg + aimg_doubles;
     std::vector<double> blk(total, 0.0);
     memcpy(&blk[o_eval], eval, sizeof(double) * n);
     memcpy(&blk[o_evec], evec, sizeof(double) * n * n);
@@ -446,6 +451,23 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
         for (int c = 0; c < C; c++)
             memcpy(&blk[o_tipc + (s * C + c) * n], &tip[(s * nclass + cls[c]) * n], sizeof(double) * n);
     memcpy(&blk[o_cls], cls.data(), sizeof(int) * C);
+    if (aimg_doubles) {
+        double *U = &blk[o_aimg], *Ui = U + (size_t)a_mt * a_ks * 64, *U4 = Ui + (size_t)a_mt * a_ks * 64, *Ui4 = U4 + (size_t)a_ks * 64;
+        for (int m = 0; m < a_mt; m++)
+            for (int ks = 0; ks < a_ks; ks++)
+                for (int l = 0; l < 64; l++) {
+                    const int row = 16 * m + (l & 15), k = 4 * ks + (l >> 4);
+                    U[((size_t)m * a_ks + ks) * 64 + l] = evec[(size_t)row * n + k];
+                    Ui[((size_t)m * a_ks + ks) * 64 + l] = inv_evec[(size_t)row * n + k];
+                }
+        if (a_tail)
+            for (int ks = 0; ks < a_ks; ks++)
+                for (int l = 0; l < 64; l++) {
+                    const int row = 16 * a_mt + (l & 3), k = 4 * ks + (l >> 4);
+                    U4[(size_t)ks * 64 + l] = evec[(size_t)row * n + k];
+                    Ui4[(size_t)ks * 64 + l] = inv_evec[(size_t)row * n + k];
+                }
+    }
     if (e->d_model && e->model_cap < total) {
         HIPCHK(hipFree(e->d_model));
         e->d_model = nullptr;
@@ -464,6 +486,8 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
     e->d_evalc = e->d_model + o_evalc;
     e->d_tipc = e->d_model + o_tipc;
     e->d_cls = reinterpret_cast<int *>(e->d_model + o_cls);
+    e->d_aimg = aimg_doubles ? e->d_model + o_aimg : nullptr;
+    e->aimg_doubles = (int)aimg_doubles;
     if (nclass > 1 || (e->n == 20 && !e->mfma_pipelined_ok)) {  // (20 states with a category count that has no
         // pipelined instantiation also run on the mixture kernel: one class)
         // MFMA A-operand images of every class for k_traverse_mfma_mix20: [class][U16 | U4 | Ui16 | Ui4][s][lane]

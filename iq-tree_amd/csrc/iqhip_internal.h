@@ -239,6 +239,13 @@ struct iqhip_engine {
     // mixture traversal kernel.  A plain model is the one-class case.
     int nclass = 1;
     double *d_evalc = nullptr;   // [ncat][n]
+    // 20 / 64 states, class 0: the A-operand fragments of U and U^-1 in the exact order of the pipelined kernels' LDS
+    // image ([U 16-row tiles][U^-1 tiles][U tail][U^-1 tail], element (m, s, lane) = row 16m + (lane & 15), column
+    // 4s + (lane >> 4)), so that a workgroup stages it with 16-byte coalesced copies: gathered element by element
+    // from evec / inv_evec the 64 KB of 64 states cost every workgroup 10-15 us before its first matrix instruction
+    // (wave trace, r02)
+    double *d_aimg = nullptr;
+    int aimg_doubles = 0;
     double *d_tipc = nullptr;    // [state_unknown+1][ncat][n]
     int *d_cls = nullptr;        // [ncat]
     double *d_img = nullptr;     // mixture A images: mix20 layout, then the generic kernel's (engine.hip)

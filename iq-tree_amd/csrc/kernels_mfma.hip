@@ -165,6 +165,7 @@ struct TravMArgs {
     const double *evalc;    // [ncat][n] eigenvalues of each category's class
     const double *tipc;     // [state][ncat][n]
     const int *cls;         // [ncat] class of each category (mixtures)
+    const double *aimg;     // class 0: fragment image of U / U^-1 in the pipelined kernels' LDS order (iqhip_engine::d_aimg)
     const double *img;      // mixture A images, k_traverse_mfma_mix20 layout [class][U16|U4|Ui16|Ui4][KS][64]
     const double *img_generic;  // ... generic kernel layout [class][U|U^-1][MT][KS][64]
     double *slab;           // [nvals][nwaves]
@@ -458,19 +459,14 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
     const int nx = A.state_unknown + 1 - N;
     double *sReg = sTipx + nx * N;
 
-    for (int t = threadIdx.x; t < MTF * KS * 64; t += WG) {
-        const int l = t & 63, ms = t >> 6, s = ms % KS, m = ms / KS;
-        const int row = 16 * m + (l & 15), k = 4 * s + (l >> 4);
-        sU[t] = A.evec[row * N + k];
-        sUi[t] = A.inv_evec[row * N + k];
-    }
-    if (TAIL4) {
-        for (int t = threadIdx.x; t < KS * 64; t += WG) {
-            const int l = t & 63, s = t >> 6;
-            const int row = 16 * MTF + (l & 3), k = 4 * s + (l >> 4);
-            sU4[t] = A.evec[row * N + k];
-            sUi4[t] = A.inv_evec[row * N + k];
-        }
+    // fragment images of U and U^-1: a straight 16-byte copy of the engine's pre-formatted image (only the 64-state
+    // instantiations read them from LDS; 20 states keep the fragments in registers, read below)
+    if constexpr (N >= 64) {
+        constexpr int NIMG2 = (2 * MTF * KS * 64 + (TAIL4 ? 2 * KS * 64 : 0)) / 2;
+        const double2 *src = reinterpret_cast<const double2 *>(A.aimg);
+        double2 *dst2 = reinterpret_cast<double2 *>(smem);
+#pragma unroll 8
+        for (int t = threadIdx.x; t < NIMG2; t += WG) dst2[t] = src[t];
     }
     if (!TAB) {
         if (TIP_COPY)
@@ -500,15 +496,15 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
     // AREG (20 states): the A fragments of U and U^-1 (16-row tile + 4-row tail: 4 x 5 doubles) stay in registers for
     // the whole launch; with them in LDS every k-step of every chain waited for an LDS round trip before its MFMAs
     constexpr bool AREG = (N < 64);
+    static_assert(!AREG || MTF == 1, "register-resident fragments: one 16-row tile (+ tail)");
     double aU[AREG ? KS : 1], aU4[AREG ? KS : 1], aUi[AREG ? KS : 1], aUi4[AREG ? KS : 1];
     if constexpr (AREG) {
 #pragma unroll
-        for (int s = 0; s < KS; s++) {
-            const int k4 = 4 * s + (lane >> 4);
-            aU[s] = A.evec[(lane & 15) * N + k4];
-            aUi[s] = A.inv_evec[(lane & 15) * N + k4];
-            aU4[s] = TAIL4 ? A.evec[(16 * MTF + (lane & 3)) * N + k4] : 0.0;
-            aUi4[s] = TAIL4 ? A.inv_evec[(16 * MTF + (lane & 3)) * N + k4] : 0.0;
+        for (int s = 0; s < KS; s++) {   // (coalesced reads of the engine's fragment image; MTF == 1 here)
+            aU[s] = A.aimg[s * 64 + lane];
+            aUi[s] = A.aimg[(MTF * KS + s) * 64 + lane];
+            aU4[s] = TAIL4 ? A.aimg[(2 * MTF * KS + s) * 64 + lane] : 0.0;
+            aUi4[s] = TAIL4 ? A.aimg[(2 * MTF * KS + KS + s) * 64 + lane] : 0.0;
         }
     }
     v4f64 prev[C][MTF];
@@ -1103,10 +1099,9 @@ __device__ __forceinline__ void trav_rows64_body(const TravMArgs &A, const int v
     // A fragments of this wave's 16 rows: lane (row = 16*wave + (lane & 15), k = 4s + (lane >> 4))
     double aU[KS], aUi[KS];
 #pragma unroll
-    for (int s = 0; s < KS; s++) {
-        const int row = 16 * wave + (lane & 15), kk = 4 * s + (lane >> 4);
-        aU[s] = A.evec[row * N + kk];
-        aUi[s] = A.inv_evec[row * N + kk];
+    for (int s = 0; s < KS; s++) {   // = M-tile `wave` of the engine's fragment image (coalesced)
+        aU[s] = A.aimg[(wave * KS + s) * 64 + lane];
+        aUi[s] = A.aimg[((4 + wave) * KS + s) * 64 + lane];
     }
     v4f64 prev = {0, 0, 0, 0};   // rows 16*wave + 4r + g of the previous result
     int prev_sc = 0;
@@ -1366,6 +1361,7 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs
     A.ops = e->d_ops;
     A.evec = e->d_evec;
     A.inv_evec = e->d_inv_evec;
+    A.aimg = e->d_aimg;
     A.tip = e->d_tip;
     A.freq = e->d_freq;
     A.invar = e->d_invar;
