@@ -264,13 +264,13 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
                     if (leafL) {
                         // tip_partial_lh[state][i] = U^-1[i][state] for state < N (phylotreesse.cpp:464-471)
                         if (MIX) bl = A.tipc[((size_t)sL * C + c) * N + i];
-                        else bl = sL < N ? sUi[aidx<KS>(i >> 4, sL >> 2, (sL & 3) * 16 + (i & 15))] : sTipx[(sL - N) * N + i];
+                        else bl = sL < N ? as_lds(sUi)[aidx<KS>(i >> 4, sL >> 2, (sL & 3) * 16 + (i & 15))] : as_lds(sTipx)[(sL - N) * N + i];
                     } else {
                         bl = vL[(size_t)c * N * 16 + s * 64 + lane];
                     }
                     if (leafR) {
                         if (MIX) br = A.tipc[((size_t)sR * C + c) * N + i];
-                        else br = sR < N ? sUi[aidx<KS>(i >> 4, sR >> 2, (sR & 3) * 16 + (i & 15))] : sTipx[(sR - N) * N + i];
+                        else br = sR < N ? as_lds(sUi)[aidx<KS>(i >> 4, sR >> 2, (sR & 3) * 16 + (i & 15))] : as_lds(sTipx)[(sR - N) * N + i];
                     } else {
                         br = vR[(size_t)c * N * 16 + s * 64 + lane];
                     }

@@ -350,7 +350,14 @@ __global__ __launch_bounds__(256) void k_newton_batch(const NewtonBatchArgs P) {
     __shared__ double s_bcast[2];
     __shared__ int s_fail;
     const int task = (int)blockIdx.x / P.G, wg = (int)blockIdx.x - task * P.G, G = P.G;
-    const NewtonTask &T = P.tasks[task];
+    // (read through the constant address space: the branch-end pointers inside are then known to be global and the first
+    // evaluation's vector reads are global_load, not flat_load with its catch-all waits)
+    typedef const __attribute__((address_space(4))) NewtonTask CTask;
+    CTask &Tc = ((CTask *)P.tasks)[task];
+    NewtonTask T;
+    T.br.a = Tc.br.a; T.br.a_states = Tc.br.a_states; T.br.b = Tc.br.b; T.br.a_sc = Tc.br.a_sc; T.br.b_sc = Tc.br.b_sc;
+    T.br.a_kind = Tc.br.a_kind; T.br.b_kind = Tc.br.b_kind; T.br.len = Tc.br.len;
+    T.xguess = Tc.xguess; T.x1 = Tc.x1; T.x2 = Tc.x2; T.xacc = Tc.xacc; T.max_steps = Tc.max_steps;
     double *theta = P.theta_base + (size_t)task * P.theta_stride;
     double *slots = P.partials + (size_t)task * 4 * G;
     unsigned int *bar = P.barriers + task;
