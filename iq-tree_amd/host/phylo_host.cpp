@@ -989,8 +989,11 @@ void PhyloTree::evaluateNNIsBatch(std::vector<NNIMove> &moves) {
         const double sf = c.n1a->lh_scale_factor + c.n2o->lh_scale_factor + sum_scale[2 * t] +
                           c.n2x->lh_scale_factor + c.n1b->lh_scale_factor + sum_scale[2 * t + 1];
         m.newloglh = res[t].lnl + sf;
-        if (res[t].optx > max_branch_length * 0.95) {
-            // diverged Newton (phylotree.cpp:2167-2176): rare; take the one-branch path for this candidate
+        const bool first_diverged = (t & 1) && res[t - 1].optx > max_branch_length * 0.95;
+        if (res[t].optx > max_branch_length * 0.95 || first_diverged) {
+            // diverged Newton (phylotree.cpp:2167-2176: optimizeOneBranch compares lnL at the optimum with lnL at the old
+            // length and may restore the latter): rare; the one-branch path for this candidate -- and for the second swap
+            // of a branch whose first swap diverged, because its starting length is whatever that comparison left
             NNIMove two[2];
             getBestNNIForBran(c.node1, c.node2, false, two);
             m = two[t & 1];
