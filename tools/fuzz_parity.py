@@ -10,21 +10,22 @@ ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 bad = 0
 for case in range(ncases):
-    n = int(rng.choice([4, 4, 20, 20, 64]))
-    seq_type = {4: 0, 20: 1, 64: 2}[n]
+    n = int(rng.choice([2, 4, 4, 20, 20, 64]))
+    seq_type = {2: 3, 4: 0, 20: 1, 64: 2}[n]
     mixture = n == 20 and rng.random() < 0.25
-    ncat = int(rng.choice([1, 2, 3, 4, 4, 5, 6, 8])) if n == 4 else (int(rng.choice([1, 2, 4, 4, 5])) if n == 20 else 1)
+    ncat = int(rng.choice([1, 2, 3, 4, 4, 5, 6, 8])) if n <= 4 else (int(rng.choice([1, 2, 4, 4, 5])) if n == 20 else 1)
     ntaxa = int(rng.integers(4, 60))
     nptn = int(rng.choice([1, 17, 64, 200, 700, 3000]))
     deep = rng.random() < 0.2
     pinv = float(rng.choice([0.0, 0.0, 0.15])) if not mixture else 0.0
     seed = int(rng.integers(1, 10 ** 6))
-    for k in ("IQHIP_SPLIT", "IQHIP_LANE_SPLIT", "IQHIP_CAT_SPLIT", "IQHIP_ROW_SPLIT"):
+    for k in ("IQHIP_SPLIT", "IQHIP_LANE_SPLIT", "IQHIP_CAT_SPLIT", "IQHIP_ROW_SPLIT", "IQHIP_LEAF_TABLES"):
         os.environ.pop(k, None)
     if rng.random() < 0.4: os.environ["IQHIP_SPLIT"] = str(int(rng.choice([0, 2, 3, 5, 9])))
     if rng.random() < 0.3: os.environ["IQHIP_LANE_SPLIT"] = str(int(rng.choice([1, 2])))
     if rng.random() < 0.3: os.environ["IQHIP_CAT_SPLIT"] = str(int(rng.choice([0, 1])))
     if rng.random() < 0.3: os.environ["IQHIP_ROW_SPLIT"] = str(int(rng.choice([0, 1])))
+    if rng.random() < 0.3: os.environ["IQHIP_LEAF_TABLES"] = str(int(rng.choice([0, 1])))
     if mixture:
         fused = rng.random() < 0.4
         model = synth.mixture_model(20, int(rng.integers(2, 5)), seed, ncat=1 if fused else int(rng.choice([1, 2, 4])), fused=fused)
