@@ -97,6 +97,7 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     e->own_stream = true;
     if (const char *ab = getenv("IQHIP_ABLATE")) e->ablate = atoi(ab);
     if (const char *h = getenv("IQHIP_HOLD")) e->use_hold = atoi(h) != 0;
+    if (const char *h = getenv("IQHIP_HOLD_LDS")) e->hold_lds = atoi(h) != 0;
     if (const char *h = getenv("IQHIP_MIXED_TOP")) e->mixed_top = atoi(h) != 0;
     if (const char *f = getenv("IQHIP_FOLD")) e->fold_reduce = atoi(f) != 0;
     if (const char *f = getenv("IQHIP_POLL")) e->poll_result = atoi(f) != 0;
@@ -888,7 +889,11 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
     // HOLD analysis (4-state kernel): a streamed left child produced by op j of this plan can stay
     // in registers until its join k if no op in (j, k) streams, loads or parks anything itself
     // (the usual case after heavier-first ordering: the other subtree is a short chain).
-    if (!e->mfma && !(e->ablate & 4) && (e->use_hold || e->lane_split != 1 || e->wg_size != 256)) {
+    const bool hold_regs = !e->mfma && !(e->ablate & 4) && (e->use_hold || e->lane_split != 1 || e->wg_size != 256);
+    // (20 states, one wave per tile: the parking place is LDS; the launch reserves it when plan_nhold > 0)
+    const bool hold_in_lds = e->mfma && e->mfma_pipelined && e->hold_lds && e->n == 20 && !e->cat_split;
+    e->plan_nhold = 0;
+    if (hold_regs || hold_in_lds) {
         std::unordered_map<const double *, int> producer;
         for (int k = 0; k < nops; k++) {
             DevOp &d = e->h_ops[k];
@@ -908,11 +913,17 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
                         d.pf = e->dummy.plh;
                         d.pf_sc = e->dummy.sc;
                         d.real_mask &= ~1;
+                        e->plan_nhold++;
                     }
                 }
             }
             producer[d.dst] = k;
         }
+    }
+    if (getenv("IQHIP_DEBUG_PLAN")) {
+        int npf = 0;
+        for (int k = 0; k < nops; k++) npf += (e->h_ops[k].left_kind == CHILD_PF) + (e->h_ops[k].right_kind == CHILD_LOAD);
+        fprintf(stderr, "[iqhip] plan: %d children read back from memory, %d parked\n", npf, e->plan_nhold);
     }
     // K2 tables of the leaf children (pipelined matrix-core kernels): slot = taxon, rebuilt by k_leaf_tables before
     // the traversal only where the pendant branch length (or the model) changed since the slot was last built
@@ -1005,6 +1016,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
             // for the 20-state kernel was measured: no gain, more chunks); IQHIP_MFMA_LDS_KB overrides
             int total_kb = 78;
             if (const char *kb = getenv("IQHIP_MFMA_LDS_KB")) total_kb = atoi(kb);
+            if (e->plan_nhold > 0) fixed += 4 * 16 * B;   // the waves' parking places (CHILD_HOLD in LDS)
             budget = (total_kb * 1024) / 8 - fixed;
         } else {
             budget = (e->lds_budget_bytes / 8) - 128 - B;

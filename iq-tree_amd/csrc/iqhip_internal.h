@@ -168,6 +168,10 @@ struct iqhip_engine {
     int lane_split_valu = 1;  // ... remembered while a 4-state engine runs a mixture on the matrix-core kernels
     bool mixed_top = true; // 64 states: mixed-role top stage (kernels_mfma.hip k_traverse_mfma_top64; IQHIP_MIXED_TOP)
     bool use_hold = true;  // 4-state traversal: park join operands in a second register set (IQHIP_HOLD)
+    // 20-state pipelined kernel: the same idea with the parking place in LDS (10 KB per wave) -- a result that is the
+    // streamed child of a later op of the same unit is kept there instead of being read back from memory (IQHIP_HOLD_LDS)
+    bool hold_lds = true;
+    int plan_nhold = 0;      // ops of the current plan whose left child is parked (diagnostics)
     int ablate = 0;        // IQHIP_ABLATE: timing-only host-side switches (results wrong when set)
     int lds_budget_bytes = 64 * 1024;  // per-workgroup LDS for the per-branch regions (IQHIP_LDS_KB)
     int plan_lds_doubles = 0;

@@ -178,6 +178,7 @@ struct TravMArgs {
     int ncat;
     int state_unknown;
     int *fold_flags;        // per result row: raised by a wave that rescaled patterns at that node (FoldArgs::flags)
+    int hold_off;           // 20-state pipelined kernel: offset (doubles) of the waves' parking places in LDS, -1: none
 };
 
 // LDS image index of A[m][s][lane]
@@ -528,6 +529,11 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
         sLn = f.sl[ptn];
         sRn = f.sr[ptn];
     }
+    // CHILD_HOLD (20 states): a result parked in LDS by the op that produced it (push_hold), in the tile layout
+    // [c][row][16 patterns], so that k-step s of category c is the 64 consecutive doubles at (c N + 4 s) 16
+    constexpr bool HOLDS = (N < 64) && (CS == 1);
+    LDS_AS double *const hold = HOLDS && A.hold_off >= 0 ? (LDS_AS double *)(smem + A.hold_off) + (size_t)wave * 16 * B + lane : nullptr;
+    int hold_sc = 0;
     v4f64 nL[MTF], nR[MTF];   // TABPF: table rows of the coming step
     double nL4 = 0.0, nR4 = 0.0;
 #pragma unroll
@@ -567,7 +573,9 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
             const int sL = sLn, sR = sRn;
             sLn = nxop.sl[ptn];
             sRn = nxop.sr[ptn];
-            if (!leafL) sc += pfn_sc;                                   // pfn_sc: valid on g == 0 lanes
+            const bool holdL = HOLDS && op.left_kind == CHILD_HOLD;
+            const bool push = HOLDS && op.push_hold;
+            if (!leafL) sc += holdL ? hold_sc : pfn_sc;                 // pfn_sc / hold_sc: valid on g == 0 lanes
             // scalar fields of the op that are needed only in its tail: requested now
             int16_t *const dst_sc = op.dst_sc;
             const int out_row = op.out_row;
@@ -626,6 +634,10 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
                         }
 #pragma unroll
                         for (int s = 0; s < KS; s++) bl[s] = PFn[s];
+                        if (HOLDS && holdL) {
+#pragma unroll
+                            for (int s = 0; s < KS; s++) bl[s] = hold[((coff + c) * N + 4 * s) * 16];
+                        }
 #pragma unroll
                         for (int s = 0; s < KS; s++) PFn[s] = nsrc[s * 64 + lane];
                         if (!TAB && leafL) {
@@ -799,6 +811,7 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
 #ifndef IQHIP_MFMA_ABLATE_NOSTORE  // timing-only build switch; never defined in the shipped library
                         dst[(size_t)((coff + c) * N + row) * 16 + p] = O[m][r];
 #endif
+                        if (HOLDS && push) hold[((coff + c) * N + 16 * m + 4 * r) * 16] = O[m][r];
                         lmax = amax_hi(lmax, O[m][r]);
                     }
                 }
@@ -807,6 +820,7 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
 #ifndef IQHIP_MFMA_ABLATE_NOSTORE
                     dst[(size_t)((coff + c) * N + 16 * MTF + g) * 16 + p] = o4;
 #endif
+                    if (HOLDS && push) hold[((coff + c) * N + 16 * MTF) * 16] = o4;
                     lmax = amax_hi(lmax, o4);
                 }
                 TRACE_STAMP();   // contraction done, stores issued
@@ -837,10 +851,12 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
                             for (int r = 0; r < 4; r++) {
                                 prev[c][m][r] *= kScalingThresholdInv;
                                 dst[(size_t)((coff + c) * N + 16 * m + 4 * r + g) * 16 + p] = prev[c][m][r];
+                                if (HOLDS && push) hold[((coff + c) * N + 16 * m + 4 * r) * 16] = prev[c][m][r];
                             }
                         if (TAIL4) {
                             prevT[c] *= kScalingThresholdInv;
                             dst[(size_t)((coff + c) * N + 16 * MTF + g) * 16 + p] = prevT[c];
+                            if (HOLDS && push) hold[((coff + c) * N + 16 * MTF) * 16] = prevT[c];
                         }
                     }
                     sc += 1;
@@ -848,6 +864,7 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
                 }
             }
             prev_sc = sc;
+            if (HOLDS && push) hold_sc = sc;
             if (lead && g == 0) dst_sc[ptn] = (int16_t)sc;
             const double ws = __any(my_scale != 0.0) ? wave_sum_m(my_scale) : 0.0;  // (no rescaling in this op: nothing to add)
             if (lead && lane == 0) {
@@ -1272,7 +1289,12 @@ template <int N, int C, int CS = 1, bool TAB = false>
 static hipError_t launch_trav_m2(iqhip_engine *e, TravMArgs &A) {
     constexpr int KS = N / 4, WG = 256;
     const int nx = e->state_unknown + 1 - N;
-    const size_t lds = (size_t)(mfma2_fixed_lds_doubles(N) + nx * N + e->plan_lds_doubles) * sizeof(double);
+    size_t lds = (size_t)(mfma2_fixed_lds_doubles(N) + nx * N + e->plan_lds_doubles) * sizeof(double);
+    A.hold_off = -1;
+    if (N < 64 && CS == 1 && e->plan_nhold > 0) {   // parking places: one tile vector (16 patterns x block) per wave
+        A.hold_off = (int)(lds / sizeof(double));
+        lds += (size_t)(WG / 64) * 16 * e->block * sizeof(double);
+    }
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma2<N, C, WG, CS, TAB>),
@@ -1381,6 +1403,7 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs
     A.ncat = e->ncat;
     A.state_unknown = e->state_unknown;
     A.fold_flags = e->d_fold_flags;
+    A.hold_off = -1;
     if (nsegs <= 0) return hipSuccess;
     if (e->mfma_pipelined && top_stage && nsegs == 1 && e->n == 64 && e->ncat == 1 && !e->row_split && e->mixed_top) {
         // whole rounds of one chain per SIMD go to full-chain workgroups, a small remainder to row-split ones
