@@ -214,6 +214,7 @@ __device__ __forceinline__ double node_update4(bool leafL, bool holdL, bool leaf
         // the same op at about the same time, so stores issued only at the end of the op reach the
         // memory system in chip-wide bursts that alternate with compute instead of overlapping it
 #ifndef IQHIP_ABLATE_NOSTORE  // timing-only build switch; never defined in the shipped library
+        // (nontemporal stores measured here: 0.178 vs 0.160 ms -- the 4-state vectors are re-read from the L2 too soon)
         *reinterpret_cast<double2 *>(dst + (2 * c) * 1024) = make_double2(prev[c * 4], prev[c * 4 + 1]);
         *reinterpret_cast<double2 *>(dst + (2 * c + 1) * 1024) = make_double2(prev[c * 4 + 2], prev[c * 4 + 3]);
 #endif
