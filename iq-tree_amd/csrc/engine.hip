@@ -168,6 +168,10 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     if (e->mfma_pipelined_ok && e->n == 20 && e->ncat == 4) {
         e->cat_split = 4 * e->ntiles <= (int64_t)e->num_cus * 4;
         if (const char *cs = getenv("IQHIP_CAT_SPLIT")) e->cat_split = atoi(cs) != 0;
+        // the dependent top stage of a staged plan with two waves per tile (two categories each, three waves per SIMD) while the
+        // alignment has only a few tiles per SIMD: 3125 tiles on 2048 two-wave slots took two rounds of full chains (-1.8 %)
+        e->top_cs2 = !e->cat_split && e->ntiles < 6 * (int64_t)e->num_cus * 4;
+        if (const char *cs = getenv("IQHIP_TOP_CS2")) e->top_cs2 = atoi(cs) != 0;
     }
     if (e->mfma_pipelined_ok && e->n == 64 && e->ncat == 1) {
         e->row_split = 4 * e->ntiles <= (int64_t)e->num_cus * 4;
@@ -902,6 +906,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
                 if (it != producer.end()) {
                     const int j = it->second;
                     bool ok = !e->h_ops[j].push_hold && seg_of[j] == seg_of[k];
+                    if (hold_in_lds && e->top_cs2 && seg_of[k] == 0) ok = false;   // (two waves per tile there: no parking place)
                     for (int q = j + 1; q < k && ok; q++) {
                         const DevOp &m = e->h_ops[q];
                         ok = m.left_kind != CHILD_PF && m.left_kind != CHILD_HOLD && m.right_kind != CHILD_LOAD &&

@@ -164,6 +164,7 @@ struct iqhip_engine {
     int wg_size = 256;     // threads per workgroup of the traversal kernel (IQHIP_WG env)
     bool row_split = false; // 64 states, 1 category: one wave per 16 output rows of a tile (small alignments)
     bool cat_split = false; // 20 states, 4 categories: one wave per category of a tile (small alignments)
+    bool top_cs2 = false;   // 20 states, 4 categories: the sequential top stage with two waves per tile (two categories each), IQHIP_TOP_CS2
     int lane_split = 1;    // 4-state traversal: lanes per pattern (2: each lane owns half of the categories)
     int lane_split_valu = 1;  // ... remembered while a 4-state engine runs a mixture on the matrix-core kernels
     bool mixed_top = true; // 64 states: mixed-role top stage (kernels_mfma.hip k_traverse_mfma_top64; IQHIP_MIXED_TOP)

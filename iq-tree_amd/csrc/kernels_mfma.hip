@@ -877,8 +877,9 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
     TRACE_END();
 }
 
+// (the two-waves-per-tile form of 20 states fits three waves per SIMD: 173 -> 168 registers without spills)
 template <int N, int C, int WG, int CS = 1, bool TAB = false>
-__global__ __launch_bounds__(WG, 2) void k_traverse_mfma2(const TravMArgs A) {
+__global__ __launch_bounds__(WG, (N == 20 && C == 2 && CS == 2) ? 3 : 2) void k_traverse_mfma2(const TravMArgs A) {
     trav_mfma2_body<N, C, WG, CS, TAB>(A, (int)blockIdx.x);
 }
 
@@ -1423,7 +1424,11 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs
             if (e->n == 64 && e->ncat == 1) return e->row_split ? launch_trav_rows64<true>(e, A) : launch_trav_m2<64, 1, 1, true>(e, A);
             return hipErrorInvalidValue;
         }
-        if (e->n == 20 && e->ncat == 4) return e->cat_split ? launch_trav_m2<20, 1, 4>(e, A) : launch_trav_m2<20, 4>(e, A);
+        if (e->n == 20 && e->ncat == 4) {
+            if (e->cat_split) return launch_trav_m2<20, 1, 4>(e, A);
+            if (e->top_cs2 && top_stage) return launch_trav_m2<20, 2, 2>(e, A);
+            return launch_trav_m2<20, 4>(e, A);
+        }
         if (e->n == 20 && e->ncat == 1) return launch_trav_m2<20, 1>(e, A);
         if (e->n == 64 && e->ncat == 1) return e->row_split ? launch_trav_rows64<false>(e, A) : launch_trav_m2<64, 1>(e, A);
         return hipErrorInvalidValue;

@@ -831,3 +831,31 @@ def test_leaf_table_variants_of_the_matrix_core_kernels(pkg, synth, oracle, n, n
     ref3, _ = ot.likelihood()
     assert abs(t.compute_likelihood() - ref3) <= LNL_RTOL * abs(ref3)
     assert check_all_vectors(t, ot) == ntaxa - 2
+
+
+@pytest.mark.parametrize("ntaxa,nsites,kw", [(40, 9000, dict(missing=0.03)), (33, 5001, dict(lo=0.25, hi=0.6)),
+                                             (64, 6000, dict(lo=0.3, hi=0.8, caterpillar=True))])
+@pytest.mark.parametrize("env", [dict(), dict(IQHIP_TOP_CS2="0"), dict(IQHIP_HOLD_LDS="0", IQHIP_TOP_CS2="1")])
+def test_protein_staged_plan_variants(pkg, synth, oracle, ntaxa, nsites, kw, env, monkeypatch):
+    """20 states x 4 categories between the small-alignment forms and the BASELINE size: staged plans (units + a dependent
+    top stage), results parked in LDS (CHILD_HOLD), and the top stage with two waves per tile (IQHIP_TOP_CS2) -- every
+    vector, counter and the derivatives against the oracle, with ragged tile counts and rescaling trees."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("IQHIP_CAT_SPLIT", "0")
+    t, ot, *_ = make_case(synth, oracle, pkg, ntaxa, nsites, 20, 4, 9900 + ntaxa, seq_type=1, **kw)
+    assert t.nptn > 4096
+    lnl = t.compute_likelihood()
+    ref, (a, b) = ot.likelihood()
+    assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+    assert check_all_vectors(t, ot) == ntaxa - 2
+    if "caterpillar" in kw:
+        assert ot.partial(a, b)[1].max() >= 1
+    df, ddf = t.compute_likelihood_derv(a, b)
+    odf, oddf = ot.derv(a, b)
+    assert abs(df - odf) <= 1e-9 * max(1.0, abs(odf)) + 1e-12 * abs(oddf)
+    assert abs(ddf - oddf) <= 1e-9 * abs(oddf)
+    # a second traversal from another root re-uses and re-parks
+    x = t.num_leaves + 3
+    y = t.neighbors(x)[0][0]
+    assert abs(t.compute_likelihood_branch(x, y) - ref) <= LNL_RTOL * abs(ref)
