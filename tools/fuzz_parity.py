@@ -1,5 +1,5 @@
 """Randomised differential run: random shapes / models / trees / memory modes through the HIP path against the
-oracle (lnL, derivatives, every vector and scale counter).  usage: python tools/fuzz_parity.py [ncases] [seed]"""
+oracle (lnL, derivatives, every vector and scale counter).  usage: [FUZZ_BIG=1] python tools/fuzz_parity.py [ncases] [seed]"""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,6 +16,13 @@ for case in range(ncases):
     ncat = int(rng.choice([1, 2, 3, 4, 4, 5, 6, 8])) if n <= 4 else (int(rng.choice([1, 2, 4, 4, 5])) if n == 20 else 1)
     ntaxa = int(rng.integers(4, 60))
     nptn = int(rng.choice([1, 17, 64, 200, 700, 3000]))
+    if os.environ.get("FUZZ_BIG"):   # staged plans of the matrix-core kernels: units, parked results, split top stages
+        n = int(rng.choice([20, 20, 64]))
+        seq_type = {20: 1, 64: 2}[n]
+        mixture = False
+        ncat = int(rng.choice([4, 4, 1])) if n == 20 else 1
+        ntaxa = int(rng.integers(14, 70))
+        nptn = int(rng.choice([5000, 9000, 17000, 21000]))
     deep = rng.random() < 0.2
     pinv = float(rng.choice([0.0, 0.0, 0.15])) if not mixture else 0.0
     seed = int(rng.integers(1, 10 ** 6))
