@@ -56,10 +56,23 @@ namespace iqhip_adapter {
 template <class X>
 struct Plan {
     std::vector<iqhip_node_op> ops;
-    std::vector<typename X::Neighbor *> dst;                /* per op; NULL for an intermediate product (degree > 3) */
-    std::vector<std::vector<typename X::Neighbor *> > kids; /* per op: the child neighbours of dst's node (else empty) */
+    std::vector<typename X::Neighbor *> dst; /* per op; NULL for an intermediate product (degree > 3) */
+    /* per op: the child neighbours of dst's node (none for an intermediate product), flat: a traversal is planned
+     * anew for every evaluation, and a vector per op (plus two per node in collectPlan) made the planning of a
+     * 50-taxon traversal cost 250 heap calls, most of its 13 us */
+    std::vector<typename X::Neighbor *> kid_flat;
+    std::vector<uint32_t> kid_off; /* [size() + 1] */
+    Plan() {
+        ops.reserve(64);
+        dst.reserve(64);
+        kid_flat.reserve(128);
+        kid_off.reserve(65);
+        kid_off.push_back(0);
+    }
     bool empty() const { return ops.empty(); }
     size_t size() const { return ops.size(); }
+    size_t nkids(size_t k) const { return kid_off[k + 1] - kid_off[k]; }
+    typename X::Neighbor *kid(size_t k, size_t i) const { return kid_flat[kid_off[k] + i]; }
 };
 
 /* Key of the intermediate product number i of the multifurcating node whose vector has key dst (see collectPlan):
@@ -122,13 +135,22 @@ inline void collectPlan(typename X::Tree *tree, typename X::Neighbor *dad_branch
         X::scaleFactor(dad_branch) = 0.0;
         return;
     }
-    std::vector<Neighbor *> kids;
+    struct KidList { /* at most 17 children (tempKey numbers the intermediate products with 5 bits) */
+        Neighbor *v[18];
+        size_t n;
+        size_t size() const { return n; }
+        Neighbor *&operator[](size_t i) { return v[i]; }
+    };
+    KidList kids;
+    kids.n = 0;
     for (int k = 0; k < X::numNeighbors(node); k++) {
         Neighbor *nb = X::neighborAt(node, k);
-        if (X::node(nb) != dad) kids.push_back(nb);
+        if (X::node(nb) != dad) {
+            if (kids.n >= 17) X::fail(tree, "collectPlan", "node of degree > 18");
+            kids.v[kids.n++] = nb;
+        }
     }
     if (kids.size() < 2) X::fail(tree, "collectPlan", "internal node with fewer than two children");
-    if (kids.size() > 17) X::fail(tree, "collectPlan", "node of degree > 18");
     if (kids.size() == 2) {
         if (!X::isLeaf(X::node(kids[0])) && X::isLeaf(X::node(kids[1]))) { /* :116-121 */
             Neighbor *t = kids[0];
@@ -139,7 +161,7 @@ inline void collectPlan(typename X::Tree *tree, typename X::Neighbor *dad_branch
     /* children first (:122-125).  Any order of independent subtrees gives the same numbers (every update is a pure
      * function of its children); with heavyFirst the subtree with more pending updates goes first, so that its
      * result waits only for the short one before it is consumed (register / cache residency in the engine). */
-    std::vector<Neighbor *> order(kids);
+    KidList order = kids;
     if (X::heavyFirst(tree)) {
         for (size_t i = 1; i < order.size(); i++) /* stable insertion sort, descending pending count */
             for (size_t j = i; j > 0 && countPending<X>(order[j], node) > countPending<X>(order[j - 1], node); j--) {
@@ -183,7 +205,9 @@ inline void collectPlan(typename X::Tree *tree, typename X::Neighbor *dad_branch
         op.flags = last ? 0u : (uint32_t)IQHIP_OP_NO_SCALE;
         plan.ops.push_back(op);
         plan.dst.push_back(last ? dad_branch : (Neighbor *)0);
-        plan.kids.push_back(last ? kids : std::vector<Neighbor *>());
+        if (last)
+            for (size_t q = 0; q < kids.size(); q++) plan.kid_flat.push_back(kids[q]);
+        plan.kid_off.push_back((uint32_t)plan.kid_flat.size());
     }
 }
 
@@ -194,7 +218,7 @@ inline void applyScaleFactors(Plan<X> &plan, const double *sum_scale) {
     for (size_t k = 0; k < plan.ops.size(); k++) {
         if (!plan.dst[k]) continue;
         double s = 0.0;
-        for (size_t i = 0; i < plan.kids[k].size(); i++) s += X::scaleFactor(plan.kids[k][i]);
+        for (size_t i = 0; i < plan.nkids(k); i++) s += X::scaleFactor(plan.kid(k, i));
         X::scaleFactor(plan.dst[k]) = s + sum_scale[k];
     }
 }

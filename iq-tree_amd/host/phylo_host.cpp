@@ -530,9 +530,9 @@ struct MirrorPolicy : iqhip_adapter::EngineCalls<MirrorPolicy, PhyloTree> {
         for (size_t k = 0; k < plan.ops.size(); k++) {
             PlanOp p;
             p.dst = plan.dst[k];
-            const bool binary = plan.dst[k] && plan.kids[k].size() == 2;
-            p.left = binary ? plan.kids[k][0] : nullptr;
-            p.right = binary ? plan.kids[k][1] : nullptr;
+            const bool binary = plan.dst[k] && plan.nkids(k) == 2;
+            p.left = binary ? plan.kid(k, 0) : nullptr;
+            p.right = binary ? plan.kid(k, 1) : nullptr;
             p.op = plan.ops[k];
             t->last_plan.push_back(p);
         }
