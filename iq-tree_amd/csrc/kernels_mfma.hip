@@ -18,10 +18,15 @@
 //     the reference's "unknown state row is exactly 1.0" (phylokernel.h:228-232) is restored
 //     by a select on the accumulators.
 // Scaling follows the SIMD rule (phylokernel.h:461-474): per pattern max |out| over the whole
-// block; the vector is stored unscaled per category and re-scaled in place in the rare case.
-// This first version reads both children from memory (L2/MALL-resident after an earlier op of
-// the same launch); keeping the previous result in registers as in the DNA kernel is the next
-// optimisation step.
+// block (taken on the high words, see kScalingThresholdHi); the vector is stored unscaled per
+// category and re-scaled in place in the rare case.
+// Kernels: k_traverse_mfma (generic category count, mixtures of 4 / 64 states: both children from
+// memory), k_traverse_mfma2 (20 and 64 states, 1 or 4 categories: previous result in registers,
+// streamed child prefetched, leaf tables, parked results in LDS, staged plans),
+// k_traverse_mfma_mix20 (20-state mixtures), k_traverse_mfma_rows64 / _top64 (64 states, a tile
+// shared by four waves), k_leaf_tables (K2), k_stream_mfma (theta, derivatives, branch lnL).
+// Cost model measured for gfx950: fp64 vector instructions add to the time of
+// the fp64 matrix instructions (same unit), 32-bit vector and LDS / memory instructions overlap.
 #include <algorithm>
 #include <type_traits>
 
