@@ -98,6 +98,7 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     if (const char *ab = getenv("IQHIP_ABLATE")) e->ablate = atoi(ab);
     if (const char *h = getenv("IQHIP_HOLD")) e->use_hold = atoi(h) != 0;
     if (const char *h = getenv("IQHIP_HOLD_LDS")) e->hold_lds = atoi(h) != 0;
+    if (const char *h = getenv("IQHIP_NEWTON_POSTS")) e->newton_posts = atoi(h) != 0;
     if (const char *h = getenv("IQHIP_MIXED_TOP")) e->mixed_top = atoi(h) != 0;
     if (const char *f = getenv("IQHIP_FOLD")) e->fold_reduce = atoi(f) != 0;
     if (const char *f = getenv("IQHIP_POLL")) e->poll_result = atoi(f) != 0;
@@ -147,8 +148,10 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
             e->num_cus = cus;
         ok = dmalloc(&e->d_newton_partials, (size_t)4 * e->num_cus) == hipSuccess &&
              dmalloc(&e->d_newton_barrier, 2) == hipSuccess && dmalloc(&e->d_fold_ticket, 4) == hipSuccess &&
+             dmalloc(&e->d_newton_posts, (size_t)2 * kNewtonPostEpochs * e->num_cus * 2) == hipSuccess &&
              dmalloc(&e->d_fold_flags, (size_t)e->result_cap) == hipSuccess;
         if (ok) hipMemsetAsync(e->d_newton_barrier, 0, 2 * sizeof(unsigned int), e->stream);
+        if (ok) hipMemsetAsync(e->d_newton_posts, 0xFF, (size_t)2 * kNewtonPostEpochs * e->num_cus * 2 * sizeof(double), e->stream);
         if (ok) hipMemsetAsync(e->d_fold_ticket, 0, 4 * sizeof(unsigned int), e->stream);
         if (ok) hipMemsetAsync(e->d_fold_flags, 0, (size_t)e->result_cap * sizeof(int), e->stream);
         if (!ok) {
@@ -207,7 +210,7 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
     }
     void *ptrs[] = {e->d_states, e->d_freq, e->d_invar, e->d_model, e->d_ops, e->d_slab,
                     e->d_theta, e->d_pattern_lh, e->d_leaf_tab, e->dummy.plh, e->dummy.sc, e->d_newton_partials,
-                    e->d_newton_barrier, e->d_fold_ticket, e->d_fold_flags, e->d_ptn_scaled, e->d_boot, e->d_img, e->d_theta_batch, e->d_batch_partials,
+                    e->d_newton_barrier, e->d_newton_posts, e->d_fold_ticket, e->d_fold_flags, e->d_ptn_scaled, e->d_boot, e->d_img, e->d_theta_batch, e->d_batch_partials,
                     e->d_batch_out, e->d_batch_barriers, e->d_batch_tasks};
     for (void *p : ptrs)
         if (p) hipFree(p);

@@ -18,6 +18,7 @@
 
 namespace iqhip {
 
+constexpr int kNewtonPostEpochs = 128;   // evaluations of one k_newton launch that have a post slot
 constexpr double kScalingThreshold = 0x1p-256;       // phylotree.h:52
 constexpr double kScalingThresholdInv = 0x1p256;     // phylotree.h:51
 // log(2^-256) as libm returns it (phylotree.h:53)
@@ -266,6 +267,12 @@ struct iqhip_engine {
     double *d_newton_partials = nullptr;   // [2][num_cus][2]
     unsigned int *d_newton_barrier = nullptr;  // [2], used alternately by consecutive k_newton launches
     unsigned int newton_launches = 0;
+    // k_newton's exchange of the workgroup partial sums without an arrival counter: every (evaluation, workgroup) has a
+    // slot of its own, {df, ddf}, that holds a sentinel until its owner posts; readers spin on the slots themselves.
+    // Two buffers alternate between launches; a launch resets the other buffer's slots of its workgroups.
+    double *d_newton_posts = nullptr;      // [2][kNewtonPostEpochs][num_cus][2]
+    unsigned int newton_post_launches = 0;
+    bool newton_posts = true;              // IQHIP_NEWTON_POSTS=0: the arrival-counter barrier of round 1
     // batched branch optimisation (iqhip_optimize_branch_batch): per-task theta buffers, partial sums, arrival
     // counters (two sets, alternating per launch), results and the task descriptors
     double *d_theta_batch = nullptr, *d_batch_partials = nullptr, *d_batch_out = nullptr;
