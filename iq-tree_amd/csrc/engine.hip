@@ -211,7 +211,7 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
     void *ptrs[] = {e->d_states, e->d_freq, e->d_invar, e->d_model, e->d_ops, e->d_slab,
                     e->d_theta, e->d_pattern_lh, e->d_leaf_tab, e->dummy.plh, e->dummy.sc, e->d_newton_partials,
                     e->d_newton_barrier, e->d_newton_posts, e->d_fold_ticket, e->d_fold_flags, e->d_ptn_scaled, e->d_boot, e->d_img, e->d_theta_batch, e->d_batch_partials,
-                    e->d_batch_out, e->d_batch_barriers, e->d_batch_tasks};
+                    e->d_batch_out, e->d_batch_barriers, e->d_batch_tasks, e->d_batch_posts};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (e->h_ops) hipHostFree(e->h_ops);
@@ -1700,6 +1700,33 @@ extern "C" int iqhip_optimize_branch_batch(iqhip_engine *e, const iqhip_branch_t
         }
         HIPCHK(hipMemcpyAsync(e->d_batch_tasks, host_tasks.data(), newton_task_bytes() * (size_t)m,
                               hipMemcpyHostToDevice, e->stream));
+        // posted exchange of the tasks' partial sums (k_newton_batch): slots of this launch, [task][evaluation][workgroup][2]
+        double *posts = nullptr, *posts_other = nullptr;
+        size_t posts_other_used = 0;
+        int post_epochs = 0;
+        if (G > 1 && e->newton_posts) {
+            int max_steps = 1;
+            for (int t = 0; t < m; t++) max_steps = std::max(max_steps, tasks[first + t].max_steps);
+            post_epochs = max_steps + 4;   // derivative evaluations + the lnL pass(es)
+            const size_t need = (size_t)m * post_epochs * G * 2;
+            if (need > e->batch_posts_cap) {
+                HIPCHK(hipStreamSynchronize(e->stream));
+                if (e->d_batch_posts) hipFree(e->d_batch_posts);
+                e->d_batch_posts = nullptr;
+                e->batch_posts_cap = 0;
+                HIPCHK(dmalloc(&e->d_batch_posts, 2 * need));
+                HIPCHK(hipMemsetAsync(e->d_batch_posts, 0xFF, 2 * need * sizeof(double), e->stream));
+                e->batch_posts_cap = need;
+                e->batch_posts_used[0] = e->batch_posts_used[1] = 0;
+            }
+            const unsigned int pp = e->batch_post_launches & 1u;
+            e->batch_post_launches++;
+            posts = e->d_batch_posts + (size_t)pp * e->batch_posts_cap;
+            posts_other = e->d_batch_posts + (size_t)(1u - pp) * e->batch_posts_cap;
+            posts_other_used = e->batch_posts_used[1u - pp];
+            e->batch_posts_used[pp] = need;
+            e->batch_posts_used[1u - pp] = 0;   // (reset by this launch)
+        }
         const unsigned int parity = e->batch_launches & 1u;
         e->batch_launches++;
         // this launch's arrival counters start at zero whatever the task counts of earlier launches were (a launch
@@ -1708,7 +1735,8 @@ extern "C" int iqhip_optimize_branch_batch(iqhip_engine *e, const iqhip_branch_t
                               e->stream));
         HIPCHK(launch_newton_batch(e, e->d_batch_tasks, m, G, e->d_theta_batch, theta_stride, e->d_batch_partials,
                                    e->d_batch_barriers + (size_t)parity * e->batch_cap,
-                                   e->d_batch_barriers + (size_t)(1u - parity) * e->batch_cap, e->d_batch_out));
+                                   e->d_batch_barriers + (size_t)(1u - parity) * e->batch_cap, e->d_batch_out, posts, posts_other,
+                                   posts_other_used, post_epochs));
         HIPCHK(hipMemcpyAsync(out.data(), e->d_batch_out, sizeof(double) * 6 * (size_t)m, hipMemcpyDeviceToHost,
                               e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));  // also: host_tasks / out are reused by the next chunk

@@ -273,6 +273,12 @@ struct iqhip_engine {
     double *d_newton_posts = nullptr;      // [2][kNewtonPostEpochs][num_cus][2]
     unsigned int newton_post_launches = 0;
     bool newton_posts = true;              // IQHIP_NEWTON_POSTS=0: the arrival-counter barrier of round 1
+    // the same for k_newton_batch: [2 launch parities][batch_posts_cap]; a launch lays its slots out as
+    // [task][evaluation][workgroup][2] and resets what the previous launch of the other parity used
+    double *d_batch_posts = nullptr;
+    size_t batch_posts_cap = 0;            // doubles per parity
+    size_t batch_posts_used[2] = {0, 0};
+    unsigned int batch_post_launches = 0;
     // batched branch optimisation (iqhip_optimize_branch_batch): per-task theta buffers, partial sums, arrival
     // counters (two sets, alternating per launch), results and the task descriptors
     double *d_theta_batch = nullptr, *d_batch_partials = nullptr, *d_batch_out = nullptr;
@@ -503,7 +509,9 @@ hipError_t launch_pattern_lh_cat(iqhip_engine *e, double len, double *out);
 // batched branch optimisation (k_newton_batch); d_tasks: device array of NewtonTask (kernels_newton.hip)
 hipError_t launch_newton_batch(iqhip_engine *e, const void *d_tasks, int ntasks, int G, double *theta_base,
                                size_t theta_stride, double *partials, unsigned int *barriers, unsigned int *barriers_next,
-                               double *out);
+                               double *out,
+                               double *posts = nullptr, double *posts_other = nullptr, size_t posts_other_used = 0,
+                               int post_epochs = 0);
 size_t newton_task_bytes();
 void newton_task_fill(void *dst, const DevBranch &br, double xguess, double x1, double x2, double xacc, int max_steps);
 

@@ -390,6 +390,12 @@ struct NewtonBatchArgs {
     unsigned int *barriers_next;  // the next launch's counters, cleared here
     double *out;                // [ntasks][6] = {optx, d2l, nsteps, status, lnl, 0}
     int G;
+    // posted exchange (see k_newton): slots [task][evaluation][workgroup][2] of this launch, sentinel = not yet posted;
+    // the first posts_other_used doubles of the other parity's buffer are reset for the launch after this one
+    double *posts;
+    double *posts_other;
+    size_t posts_other_used;
+    int post_epochs;
 };
 
 __global__ __launch_bounds__(256) void k_newton_batch(const NewtonBatchArgs P) {
@@ -415,6 +421,9 @@ __global__ __launch_bounds__(256) void k_newton_batch(const NewtonBatchArgs P) {
         s_fail = 0;
         if (wg == 0) __hip_atomic_store(P.barriers_next + task, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (P.posts)
+        for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < P.posts_other_used; t += (size_t)gridDim.x * 256)
+            reinterpret_cast<unsigned long long *>(P.posts_other)[t] = ~0ull;
     unsigned int epoch = 0;
     bool first = true;
     // sums over the task's patterns of (f*df, f*ddf) -- or of f*log|lh| when lnl_pass -- at branch length x
@@ -433,7 +442,43 @@ __global__ __launch_bounds__(256) void k_newton_batch(const NewtonBatchArgs P) {
         else if (first) wg_partial<true, 0>(A, theta, T.br, wg, G, s_v0, s_v1, s_v2, s_red, p0, p1);
         else wg_partial<false, 0>(A, theta, T.br, wg, G, s_v0, s_v1, s_v2, s_red, p0, p1);
         first = false;
-        if (G > 1) {
+        if (G > 1 && P.posts) {
+            unsigned long long *ps = reinterpret_cast<unsigned long long *>(P.posts) +
+                                     ((size_t)task * P.post_epochs + epoch) * G * 2;
+            if (threadIdx.x == 0) {
+                unsigned long long ua = __double_as_longlong(p0), ub = __double_as_longlong(p1);
+                if (ua == ~0ull) ua = 0x7ff8000000000000ull;
+                if (ub == ~0ull) ub = 0x7ff8000000000000ull;
+                __hip_atomic_store(&ps[2 * wg], ua, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ps[2 * wg + 1], ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (threadIdx.x < 64) {
+                double a = 0.0, b = 0.0;
+                long spins = 0;
+                for (;;) {
+                    bool ready = true;
+                    a = 0.0; b = 0.0;
+                    for (int w = threadIdx.x; w < G; w += 64) {
+                        const unsigned long long ua = __hip_atomic_load(&ps[2 * w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long ub = __hip_atomic_load(&ps[2 * w + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ready = ready && ua != ~0ull && ub != ~0ull;
+                        a += __longlong_as_double(ua);
+                        b += __longlong_as_double(ub);
+                    }
+                    if (__all(ready)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > 2000000L) { if (threadIdx.x == 0) s_fail = 1; break; }  // never hang the GPU
+                }
+                a = wsum(a);
+                b = wsum(b);
+                if (threadIdx.x == 0) { s_bcast[0] = a; s_bcast[1] = b; }
+            }
+            __syncthreads();
+            p0 = s_bcast[0];
+            p1 = s_bcast[1];
+            __syncthreads();
+            epoch++;
+        } else if (G > 1) {
             double *slot = slots + (size_t)(epoch & 1) * G * 2;
             if (threadIdx.x == 0) {
                 __hip_atomic_store(&slot[2 * wg], p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -545,7 +590,7 @@ void newton_task_fill(void *dst, const DevBranch &br, double xguess, double x1, 
 
 hipError_t launch_newton_batch(iqhip_engine *e, const void *d_tasks, int ntasks, int G, double *theta_base,
                                size_t theta_stride, double *partials, unsigned int *barriers, unsigned int *barriers_next,
-                               double *out) {
+                               double *out, double *posts, double *posts_other, size_t posts_other_used, int post_epochs) {
     NewtonBatchArgs P;
     NewtonArgs &A = P.c;
     A.theta = nullptr;
@@ -580,6 +625,10 @@ hipError_t launch_newton_batch(iqhip_engine *e, const void *d_tasks, int ntasks,
     P.barriers_next = barriers_next;
     P.out = out;
     P.G = G;
+    P.posts = posts;
+    P.posts_other = posts_other;
+    P.posts_other_used = posts_other_used;
+    P.post_epochs = post_epochs;
     const size_t lds = (size_t)(3 * e->block + 8) * sizeof(double);
     BarrierLaunchGuard guard(e, G > 1);
     hipLaunchKernelGGL(k_newton_batch, dim3((unsigned)(ntasks * G)), dim3(256), lds, e->stream, P);
