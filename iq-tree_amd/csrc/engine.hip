@@ -99,6 +99,7 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     if (const char *h = getenv("IQHIP_HOLD")) e->use_hold = atoi(h) != 0;
     if (const char *h = getenv("IQHIP_HOLD_LDS")) e->hold_lds = atoi(h) != 0;
     if (const char *h = getenv("IQHIP_NEWTON_POSTS")) e->newton_posts = atoi(h) != 0;
+    if (const char *h = getenv("IQHIP_SMALL_PLANS")) e->small_plans = atoi(h) != 0;
     if (const char *h = getenv("IQHIP_MIXED_TOP")) e->mixed_top = atoi(h) != 0;
     if (const char *f = getenv("IQHIP_FOLD")) e->fold_reduce = atoi(f) != 0;
     if (const char *f = getenv("IQHIP_POLL")) e->poll_result = atoi(f) != 0;
@@ -1082,6 +1083,13 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
     e->last_segs = segs_in;
     e->last_plan_version = e->keymap_version;  // (slabs created while building are included)
     e->last_plan_dst = prev_dst;
+    // a small plan of the 4-state kernel rides in the kernel arguments (launch_traverse4 copies it out of h_ops)
+    e->plan_small = e->small_plans && !e->mfma && !explicit_segs && units.empty() && nops > 0 && nops + kSentinels <= kSmallPlanOps;
+    e->plan_small_nops = nops;
+    if (e->plan_small) {
+        e->uploaded_plan.assign((const char *)e->h_ops, (const char *)e->h_ops + nbytes);   // (what d_ops would hold)
+        return IQHIP_OK;
+    }
     if (e->uploaded_plan.size() == nbytes && memcmp(e->uploaded_plan.data(), e->h_ops, nbytes) == 0)
         return IQHIP_OK;
     HIPCHK(hipMemcpyAsync(e->d_ops, e->h_ops, nbytes, hipMemcpyHostToDevice, e->stream));

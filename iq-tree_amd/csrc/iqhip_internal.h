@@ -18,6 +18,7 @@
 
 namespace iqhip {
 
+constexpr int kSmallPlanOps = 4;         // op descriptors (incl. the two look-ahead sentinels) that fit the kernel arguments
 constexpr int kNewtonPostEpochs = 128;   // evaluations of one k_newton launch that have a post slot
 constexpr double kScalingThreshold = 0x1p-256;       // phylotree.h:52
 constexpr double kScalingThresholdInv = 0x1p256;     // phylotree.h:51
@@ -179,6 +180,12 @@ struct iqhip_engine {
     int plan_lds_doubles = 0;
     int plan_state_slots = 1;    // leaf-state LDS slots of the largest chunk (4-state path)
     bool plan_has_load = false;  // some op has two memory children (slow kernel instantiation)
+    // 4-state kernel: a plan of at most kSmallPlanOps - 2 ops with no units travels in the kernel arguments instead of
+    // being copied to d_ops first (the copy kernel and the dependent-launch gap behind it cost ~9 us per changed plan,
+    // i.e. per branch of a branch-length sweep); IQHIP_SMALL_PLANS=0 switches it off
+    bool plan_small = false;
+    int plan_small_nops = 0;
+    bool small_plans = true;
     // Staged plans (engine.hip, build_plan): independent subtrees ("units") run as their own workgroups in a
     // first launch, the ops above them ("top") in a second one.  Segment table on the device, after the
     // sentinel descriptors: {top_begin, top_nops, unit1_begin, unit1_nops, ...}

@@ -101,6 +101,10 @@ struct Trav4Args {
     int has_load;
     FoldArgs fold;
     DevBranch root;
+    // a small plan inside the kernel arguments (iqhip_engine::plan_small): ops + look-ahead sentinels, one segment
+    int small_plan;
+    int small_segs[2];
+    DevOp small_ops[kSmallPlanOps];
 };
 
 // a[x] (x = 0..3) of a LEAF child for category c: table row (fast path) or E*tip evaluated on
@@ -273,7 +277,10 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // make it provably uniform
     const int seg = (int)blockIdx.x / A.ngroups;  // scalar
-    const int k_begin = as_const(A.segs)[2 * seg], k_end = k_begin + as_const(A.segs)[2 * seg + 1];
+    // (a small plan is read out of the kernel-argument segment, which is constant memory like the plan buffer)
+    const CONST_AS char *kargs = (const CONST_AS char *)__builtin_amdgcn_kernarg_segment_ptr();
+    const CONST_AS int *segs = A.small_plan ? (const CONST_AS int *)(kargs + offsetof(Trav4Args, small_segs)) : as_const(A.segs);
+    const int k_begin = segs[2 * seg], k_end = k_begin + segs[2 * seg + 1];
     // wave -> (tile, 32-pattern half); lane -> (pattern, category half)
     const int64_t wtile = (int64_t)((int)blockIdx.x - seg * A.ngroups) * WPB + wave;
     const bool active = wtile < A.ntiles * SP;
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
 
     const CONST_AS double *U = as_const(A.evec);
     const CONST_AS double *uinv = as_const(A.inv_evec);
-    const CONST_AS DevOp *ops = as_const(A.ops);
+    const CONST_AS DevOp *ops = A.small_plan ? (const CONST_AS DevOp *)(kargs + offsetof(Trav4Args, small_ops)) : as_const(A.ops);
 
     double prev[BL], PF[BL], HOLD[USE_HOLD ? BL : 1];
     int hold_sc = 0;
@@ -322,14 +329,14 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
         __syncthreads();  // the previous chunk's regions are no longer read
         for (int t = threadIdx.x; t < kn * 2 * B; t += WG) {  // phase 1: exponentials
             const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B;
-            const DevOp &d = A.ops[k + o];
+            const CONST_AS DevOp &d = ops[k + o];
             const double len = child ? d.right_len : d.left_len;
             s_reg[(child ? d.lds_right : d.lds_left) + e] = exp(A.eval[e & 3] * (A.rates[e >> 2] * len));
         }
         __syncthreads();
         for (int t = threadIdx.x; t < kn * 2 * 5 * B; t += WG) {  // phase 2: leaf tables (K2)
             const int o = t / (10 * B), r = t - o * (10 * B), child = r / (5 * B), q = r - child * (5 * B);
-            const DevOp &d = A.ops[k + o];
+            const CONST_AS DevOp &d = ops[k + o];
             if ((child ? d.right_kind : d.left_kind) != CHILD_LEAF) continue;
             const int row = q / B, e = q - row * B, c = e >> 2, x = e & 3;
             double *reg = s_reg + (child ? d.lds_right : d.lds_left);
@@ -559,6 +566,15 @@ hipError_t launch_traverse4(iqhip_engine *e, const int *seg_table, int nsegs, bo
     A.has_root = root ? 1 : 0;
     A.lds_reg_doubles = e->plan_lds_doubles;
     if (root) A.root = *root; else A.root = DevBranch{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.0};
+    A.small_plan = 0;
+    A.small_segs[0] = A.small_segs[1] = 0;
+    if (e->plan_small && nsegs == 1) {   // (the plan was not copied to d_ops: it travels with the launch)
+        A.small_plan = 1;
+        A.small_segs[1] = e->plan_small_nops;
+        for (int q = 0; q < kSmallPlanOps; q++) A.small_ops[q] = e->h_ops[q];
+    } else {
+        for (int q = 0; q < kSmallPlanOps; q++) A.small_ops[q] = DevOp{};
+    }
     switch (e->ncat) {
         case 1: return launch_trav_wg<1>(e, A);
         case 2: return launch_trav_wg<2>(e, A);
