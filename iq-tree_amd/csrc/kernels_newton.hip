@@ -67,6 +67,10 @@ struct NewtonArgs {
     double *partials;        // [2 parities][grid][2]
     double *posts;           // non-NULL: posted exchange, this launch's slots [kNewtonPostEpochs][grid][2] (sentinel = not yet)
     double *posts_other;     // the other launch parity's slots: reset here for the launch after this one
+    // non-NULL: the result vector is mapped host memory; workgroup 0 publishes this sequence number when everything the
+    // host will read has been written, and the host polls it instead of paying a stream synchronisation (read_result)
+    volatile unsigned long long *done;
+    unsigned long long seq;
     unsigned int *barrier;   // arrival counter of this launch (zero at its start), counts up over the epochs
     unsigned int *barrier_next;  // the next launch's counter
     double *out;             // {optx, d2l, nsteps, status}
@@ -210,6 +214,8 @@ __global__ __launch_bounds__(256) void k_newton(const NewtonArgs A) {
             if (threadIdx.x == 0) A.result[2 + r] = s_rr[0];
             __syncthreads();
         }
+        // (the rows are host-visible before this workgroup's first post, hence before workgroup 0 publishes `done`)
+        if (A.done && threadIdx.x == 0) __threadfence_system();
     }
     // posted exchange: the slots the NEXT launch will use (the other parity) go back to the sentinel; nobody reads
     // them during this launch
@@ -362,6 +368,10 @@ __global__ __launch_bounds__(256) void k_newton(const NewtonArgs A) {
         A.out[1] = d2l;
         A.out[2] = (double)nsteps;
         A.out[3] = (double)status;
+        if (A.done) {
+            __threadfence_system();
+            *A.done = A.seq;
+        }
     }
 }
 
@@ -708,6 +718,15 @@ hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, d
     A.barrier = e->d_newton_barrier + (e->newton_launches & 1);
     A.barrier_next = e->d_newton_barrier + ((e->newton_launches + 1) & 1);
     e->newton_launches++;
+    A.done = nullptr;
+    A.seq = 0;
+    // (a single workgroup reduces all rows itself; several need the posted exchange in between -- the counter form
+    // gives the same ordering, the rows are written before the workgroup's first arrival)
+    if (e->poll_result && e->d_result == e->d_result_own && out >= e->d_result && out < e->d_result + e->result_cap) {
+        A.seq = ++e->result_seq;
+        A.done = e->d_done;
+        e->poll_pending = true;
+    }
     A.posts = A.posts_other = nullptr;
     if (grid > 1 && e->newton_posts && max_steps + 3 <= kNewtonPostEpochs) {
         const size_t per = (size_t)kNewtonPostEpochs * e->num_cus * 2;   // (slots are indexed with the launch's grid <= num_cus)
