@@ -1668,6 +1668,7 @@ extern "C" int iqhip_optimize_branch_batch(iqhip_engine *e, const iqhip_branch_t
             if ((size_t)chunk > fit) chunk = (int)fit;
         }
     }
+    if (const char *bc = getenv("IQHIP_BATCH_CHUNK")) chunk = std::max(1, std::min(chunk, atoi(bc)));
     const int G = std::max(1, std::min(wgs_needed, capacity / chunk));
     const size_t theta_stride = (size_t)e->nptn_pad * e->block;
     if ((size_t)chunk * theta_stride > e->theta_batch_cap) {
