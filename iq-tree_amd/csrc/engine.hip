@@ -1207,6 +1207,11 @@ static int read_result(iqhip_engine *e, int ndoubles) {
             if (*e->h_done == want) {
                 std::atomic_thread_fence(std::memory_order_acquire);
                 e->staging_busy = false;  // (in-order stream: the plan upload finished long before k_reduce)
+                if (e->folded_rows >= 0) {   // folded reduction: unflagged sum_scale rows were not written (fold_tail)
+                    if (e->h_result[2 + e->folded_rows] == 0.0)
+                        for (int k = 0; k < e->folded_rows; k++) e->h_result[2 + k] = 0.0;
+                    e->folded_rows = -1;
+                }
                 return IQHIP_OK;
             }
             __builtin_ia32_pause();
@@ -1215,6 +1220,11 @@ static int read_result(iqhip_engine *e, int ndoubles) {
     e->poll_pending = false;
     HIPCHK(hipStreamSynchronize(e->stream));
     e->staging_busy = false;
+    if (e->folded_rows >= 0) {
+        if (e->h_result[2 + e->folded_rows] == 0.0)
+            for (int k = 0; k < e->folded_rows; k++) e->h_result[2 + k] = 0.0;
+        e->folded_rows = -1;
+    }
     return IQHIP_OK;
 }
 

@@ -331,6 +331,9 @@ struct iqhip_engine {
     size_t tev_used = 0;
     int64_t tev_launches = 0;  // traversal-kernel launches inside the recorded brackets
     int last_nops = 0;
+    // the last submission's reduction was folded into its kernel and the host polls: the kernel wrote only the rows it
+    // summed plus, behind them, the number of flagged sum_scale rows; read_result zero-fills the rest when that is 0
+    int folded_rows = -1;
 };
 
 namespace iqhip {
@@ -353,6 +356,9 @@ struct FoldArgs {
     int nrows_scale;       // sum_scale rows (2 .. 2+nrows_scale)
     int root_rows;         // 0: none; 2: rows 0 and 1 hold the root-branch sums
     int enabled;
+    // non-NULL: result is mapped host memory; the last workgroup publishes this sequence number for the polling host
+    volatile unsigned long long *done;
+    unsigned long long seq;
 };
 
 #if defined(__HIPCC__)
@@ -384,14 +390,28 @@ __device__ inline void fold_tail(const FoldArgs &F) {
     auto sum_row = [&](int row) {
         const double *r = F.slab + (size_t)row * F.nwaves;
         if (threadIdx.x < 64) {
+            // the four strided running sums of this lane, 8 terms of each at a time: all 32 loads are in flight
+            // together (one round trip), the additions keep k_reduce's order
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int base = 0; base < F.nwaves; base += 8 * 256) {
+                double v[4][8];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int v = (int)threadIdx.x + 64 * j;
-                double acc = 0.0;
-                for (int i = v; i < F.nwaves; i += 256)
-                    acc += __hip_atomic_load(&r[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_f[v] = acc;
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const int i = base + q * 256 + (int)threadIdx.x + 64 * j;
+                        v[j][q] = i < F.nwaves ? __hip_atomic_load(&r[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                    }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const int i = base + q * 256 + (int)threadIdx.x + 64 * j;
+                        if (i < F.nwaves) acc[j] += v[j][q];
+                    }
             }
+#pragma unroll
+            for (int j = 0; j < 4; j++) s_f[(int)threadIdx.x + 64 * j] = acc[j];
         }
         __syncthreads();
 #pragma unroll
@@ -405,9 +425,13 @@ __device__ inline void fold_tail(const FoldArgs &F) {
     };
     if (F.root_rows) {
         sum_row(0);
-        sum_row(1);
+        if (F.root_rows > 1) sum_row(1);
+        else if (threadIdx.x == 0) F.result[1] = 0.0;   // (no +ASC: the prob_const row is zero)
     }
-    // sum_scale rows, 256 at a time: the lanes look at the flags side by side, unflagged rows are 0.0 at once
+    // sum_scale rows, 256 at a time: the lanes look at the flags side by side.  With a polling host (F.done) the
+    // unflagged rows are not written at all -- 48 stores over PCIe for a 50-taxon plan -- only their count is (the host
+    // fills in the zeros, read_result); a device-resident result vector (collectives) gets every row.
+    int nflagged = 0;
     for (int base = 2; base < nrows; base += 256) {
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
@@ -419,7 +443,7 @@ __device__ inline void fold_tail(const FoldArgs &F) {
                     if (__hip_atomic_load(&F.flags[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                         s_rows[atomicAdd(&s_n, 1)] = row;
                         __hip_atomic_store(&F.flags[row], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else {
+                    } else if (!F.done) {
                         F.result[row] = 0.0;
                     }
                 }
@@ -427,9 +451,28 @@ __device__ inline void fold_tail(const FoldArgs &F) {
         }
         __syncthreads();
         const int n = s_n;
+        nflagged += n;
+        if (n > 0 && F.done) {   // some rows are non-zero: the host will read all of them
+            if (threadIdx.x < 64)
+                for (int j = 0; j < 4; j++) {
+                    const int row = base + (int)threadIdx.x + 64 * j;
+                    if (row < nrows) {
+                        bool flagged = false;
+                        for (int q = 0; q < n; q++) flagged = flagged || s_rows[q] == row;
+                        if (!flagged) F.result[row] = 0.0;
+                    }
+                }
+        }
         for (int q = 0; q < n; q++) sum_row(s_rows[q]);
     }
-    if (threadIdx.x == 0) __hip_atomic_store(F.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (F.done && threadIdx.x == 0) F.result[nrows] = (double)nflagged;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(F.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (F.done) {
+            __threadfence_system();
+            *F.done = F.seq;
+        }
+    }
 }
 #endif
 

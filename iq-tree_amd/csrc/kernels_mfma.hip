@@ -1600,6 +1600,8 @@ hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, do
     A.fold.nrows_scale = fold_rows > 0 ? fold_rows : 0;
     A.fold.root_rows = 2;
     A.fold.enabled = (fold_rows >= 0 && mode != 1 && e->n_unobs == 0) ? 1 : 0;
+    A.fold.done = nullptr;
+    A.fold.seq = 0;
     if (br) A.br = *br; else A.br = DevBranch{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.0};
     A.tip = e->d_tipc;
     A.eval = e->d_evalc;

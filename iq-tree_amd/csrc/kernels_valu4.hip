@@ -542,8 +542,16 @@ hipError_t launch_traverse4(iqhip_engine *e, const int *seg_table, int nsegs, bo
     A.fold.flags = e->d_fold_flags;
     A.fold.nwaves = nwaves;
     A.fold.nrows_scale = fold_rows > 0 ? fold_rows : 0;
-    A.fold.root_rows = root ? 2 : 0;
+    A.fold.root_rows = root ? (e->n_unobs > 0 ? 2 : 1) : 0;
     A.fold.enabled = (fold_rows >= 0 && e->wg_size == 256) ? 1 : 0;
+    A.fold.done = nullptr;
+    A.fold.seq = 0;
+    if (A.fold.enabled && e->poll_result && e->d_result == e->d_result_own) {   // mapped host memory: the host may poll
+        A.fold.seq = ++e->result_seq;
+        A.fold.done = e->d_done;
+        e->poll_pending = true;
+        e->folded_rows = A.fold.nrows_scale;
+    }
     A.ops = e->d_ops;
     A.evec = e->d_evec;
     A.inv_evec = e->d_inv_evec;
