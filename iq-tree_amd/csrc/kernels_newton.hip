@@ -89,6 +89,21 @@ struct NewtonArgs {
     int max_steps;
 };
 
+// sum over the four lane groups of a pattern (lanes p, p+16, p+32, p+48) with gfx950's permlane swaps instead of
+// ds_bpermute: swap(x, x) hands every lane its partner's value; (x + x^16) + (that of the lanes ^32), the order of
+// the shuffle form (fp addition commutes), so the bits are the same
+__device__ __forceinline__ double group_sum(double v) {
+    unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    lo = __double2loint(v);
+    hi = __double2hiint(v);
+    auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
+}
+
 __device__ __forceinline__ double wsum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -145,21 +160,35 @@ __device__ __forceinline__ void wg_partial(const NewtonArgs &A, const double *th
                 if (br.a_kind == CHILD_LEAF) tp = A.tipc + (size_t)br.a_states[ptn] * B;
                 else av = br.a + (size_t)tile * 16 * B;
             }
-            for (int e = g; e < B; e += 4) {
-                double t;
-                if (BUILD) {
-                    t = (tp ? tp[e] : av[(size_t)e * 16 + p]) * bv[(size_t)e * 16 + p];
-                    const_cast<double *>(th)[(size_t)e * 16 + p] = t;
-                } else {
-                    t = th[(size_t)e * 16 + p];
+            // (unrolled: the loads of several rows are in flight together; the accumulation order is unchanged)
+            // a pattern's rows 20 at a time: all 20 loads of a lane are in flight together (one L2 round trip per
+            // 80 block entries instead of one per unrolled handful); the accumulation order is unchanged
+            for (int e0 = g; e0 < B; e0 += 80) {
+                double tv[20];
+#pragma unroll
+                for (int q = 0; q < 20; q++) {
+                    const int e = e0 + 4 * q;
+                    if (e < B) {
+                        if (BUILD) tv[q] = (tp ? tp[e] : av[(size_t)e * 16 + p]) * bv[(size_t)e * 16 + p];
+                        else tv[q] = th[(size_t)e * 16 + p];
+                    } else {
+                        tv[q] = 0.0;
+                    }
                 }
-                lh = fma(s_v0[e], t, lh);
-                d1 = fma(s_v1[e], t, d1);
-                d2 = fma(s_v2[e], t, d2);
+#pragma unroll
+                for (int q = 0; q < 20; q++) {
+                    const int e = e0 + 4 * q;
+                    if (e < B) {
+                        if (BUILD) const_cast<double *>(th)[(size_t)e * 16 + p] = tv[q];
+                        lh = fma(s_v0[e], tv[q], lh);
+                        d1 = fma(s_v1[e], tv[q], d1);
+                        d2 = fma(s_v2[e], tv[q], d2);
+                    }
+                }
             }
-            lh += __shfl_xor(lh, 16, 64); lh += __shfl_xor(lh, 32, 64);
-            d1 += __shfl_xor(d1, 16, 64); d1 += __shfl_xor(d1, 32, 64);
-            d2 += __shfl_xor(d2, 16, 64); d2 += __shfl_xor(d2, 32, 64);
+            lh = group_sum(lh);
+            d1 = group_sum(d1);
+            d2 = group_sum(d2);
         }
         if (mine) {
             lh += A.invar[ptn];
