@@ -1084,7 +1084,9 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
     e->last_plan_version = e->keymap_version;  // (slabs created while building are included)
     e->last_plan_dst = prev_dst;
     // a small plan of the 4-state kernel rides in the kernel arguments (launch_traverse4 copies it out of h_ops)
-    e->plan_small = e->small_plans && !e->mfma && !explicit_segs && units.empty() && nops > 0 && nops + kSentinels <= kSmallPlanOps;
+    // (matrix-core path: the pipelined 20-state kernels without leaf tables -- tables come with a job list in the buffer)
+    const bool small_kernel = !e->mfma || (e->mfma_pipelined && e->n == 20 && !e->leaf_tables && e->plan_nleaf_tabs == 0);
+    e->plan_small = e->small_plans && small_kernel && !explicit_segs && units.empty() && nops > 0 && nops + kSentinels <= kSmallPlanOps;
     e->plan_small_nops = nops;
     if (e->plan_small) {
         e->uploaded_plan.assign((const char *)e->h_ops, (const char *)e->h_ops + nbytes);   // (what d_ops would hold)

@@ -184,6 +184,10 @@ struct TravMArgs {
     int state_unknown;
     int *fold_flags;        // per result row: raised by a wave that rescaled patterns at that node (FoldArgs::flags)
     int hold_off;           // 20-state pipelined kernel: offset (doubles) of the waves' parking places in LDS, -1: none
+    // a small plan inside the kernel arguments (iqhip_engine::plan_small; read by trav_mfma2_body only)
+    int small_plan;
+    int small_segs[2];
+    DevOp small_ops[kSmallPlanOps];
 };
 
 // LDS image index of A[m][s][lane]
@@ -483,7 +487,11 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seg = vblock / A.ngroups;  // scalar
-    const int k_begin = as_const(A.segs)[2 * seg], k_end = k_begin + as_const(A.segs)[2 * seg + 1];
+    // (a small plan is read out of the kernel-argument segment, constant memory like the plan buffer; A is the
+    // kernel's only parameter -- k_traverse_mfma2 -- so its members sit at their struct offsets there)
+    const CONST_AS char *kargs = (const CONST_AS char *)__builtin_amdgcn_kernarg_segment_ptr();
+    const CONST_AS int *segs = A.small_plan ? (const CONST_AS int *)(kargs + offsetof(TravMArgs, small_segs)) : as_const(A.segs);
+    const int k_begin = segs[2 * seg], k_end = k_begin + segs[2 * seg + 1];
     const int64_t tile = (int64_t)(vblock - seg * A.ngroups) * (WPB / CS) + wave / CS;
     const int coff = (wave % CS) * C;          // first category of this wave
     const bool lead = (wave % CS) == 0;        // the wave that owns the tile's counters and sums
@@ -494,7 +502,7 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
     const size_t tbase = (size_t)tl * 16 * B;     // doubles into a vector slab
     const double freq = A.freq[ptn];
     const double invar = A.invar[ptn];
-    const CONST_AS DevOp *ops = as_const(A.ops);
+    const CONST_AS DevOp *ops = A.small_plan ? (const CONST_AS DevOp *)(kargs + offsetof(TravMArgs, small_ops)) : as_const(A.ops);
     const int S = A.state_unknown;                // rows of a leaf table
     TRACE_DECL;
     TRACE_BEGIN(vblock, wave, N);
@@ -1310,6 +1318,12 @@ static hipError_t launch_trav_m2(iqhip_engine *e, TravMArgs &A) {
     }
     A.ngroups = (int)((A.ntiles * CS + 3) / 4);
     const int grid = A.ngroups * A.nsegs_launch;
+    if (e->plan_small && A.nsegs_launch == 1) {   // (the plan was not copied to d_ops: it travels with the launch)
+        A.small_plan = 1;
+        A.small_segs[0] = 0;
+        A.small_segs[1] = e->plan_small_nops;
+        for (int q = 0; q < kSmallPlanOps; q++) A.small_ops[q] = e->h_ops[q];
+    }
     (void)hipGetLastError();
     hipLaunchKernelGGL((k_traverse_mfma2<N, C, WG, CS, TAB>), dim3(grid), dim3(WG), lds, e->stream, A);
     return hipGetLastError();
@@ -1411,6 +1425,9 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs
     A.state_unknown = e->state_unknown;
     A.fold_flags = e->d_fold_flags;
     A.hold_off = -1;
+    A.small_plan = 0;
+    A.small_segs[0] = A.small_segs[1] = 0;
+    for (int q = 0; q < kSmallPlanOps; q++) A.small_ops[q] = DevOp{};
     if (nsegs <= 0) return hipSuccess;
     if (e->mfma_pipelined && top_stage && nsegs == 1 && e->n == 64 && e->ncat == 1 && !e->row_split && e->mixed_top) {
         // whole rounds of one chain per SIMD go to full-chain workgroups, a small remainder to row-split ones
