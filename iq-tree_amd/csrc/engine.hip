@@ -149,10 +149,10 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
             e->num_cus = cus;
         ok = dmalloc(&e->d_newton_partials, (size_t)4 * e->num_cus) == hipSuccess &&
              dmalloc(&e->d_newton_barrier, 2) == hipSuccess && dmalloc(&e->d_fold_ticket, 4) == hipSuccess &&
-             dmalloc(&e->d_newton_posts, (size_t)2 * kNewtonPostEpochs * e->num_cus * 2) == hipSuccess &&
+             dmalloc(&e->d_newton_posts, (size_t)2 * kNewtonPostEpochs * (2 * e->num_cus) * 2) == hipSuccess &&
              dmalloc(&e->d_fold_flags, (size_t)e->result_cap) == hipSuccess;
         if (ok) hipMemsetAsync(e->d_newton_barrier, 0, 2 * sizeof(unsigned int), e->stream);
-        if (ok) hipMemsetAsync(e->d_newton_posts, 0xFF, (size_t)2 * kNewtonPostEpochs * e->num_cus * 2 * sizeof(double), e->stream);
+        if (ok) hipMemsetAsync(e->d_newton_posts, 0xFF, (size_t)2 * kNewtonPostEpochs * (2 * e->num_cus) * 2 * sizeof(double), e->stream);
         if (ok) hipMemsetAsync(e->d_fold_ticket, 0, 4 * sizeof(unsigned int), e->stream);
         if (ok) hipMemsetAsync(e->d_fold_flags, 0, (size_t)e->result_cap * sizeof(int), e->stream);
         if (!ok) {

@@ -741,9 +741,13 @@ hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, d
     A.x2 = x2;
     A.xacc = xacc;
     A.max_steps = max_steps;
-    // one workgroup per CU at most: every workgroup must be resident for the grid barrier
-    int64_t wgs = (e->ntiles + 3) / 4;
-    int grid = (int)(wgs < 1 ? 1 : (wgs > e->num_cus ? e->num_cus : wgs));
+    // every workgroup must be resident for the exchange: one per CU with the arrival counter (its slots are sized for that),
+    // two per CU with the posted exchange (125 registers, little LDS: four would fit), so that a 100 k-pattern alignment
+    // has one tile per wave and a derivative pass is one round trip
+    const bool posts = e->newton_posts && max_steps + 3 <= kNewtonPostEpochs;
+    const int64_t wgs = (e->ntiles + 3) / 4;
+    const int64_t max_grid = posts ? 2 * (int64_t)e->num_cus : e->num_cus;
+    int grid = (int)(wgs < 1 ? 1 : (wgs > max_grid ? max_grid : wgs));
     A.barrier = e->d_newton_barrier + (e->newton_launches & 1);
     A.barrier_next = e->d_newton_barrier + ((e->newton_launches + 1) & 1);
     e->newton_launches++;
@@ -757,8 +761,8 @@ hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, d
         e->poll_pending = true;
     }
     A.posts = A.posts_other = nullptr;
-    if (grid > 1 && e->newton_posts && max_steps + 3 <= kNewtonPostEpochs) {
-        const size_t per = (size_t)kNewtonPostEpochs * e->num_cus * 2;   // (slots are indexed with the launch's grid <= num_cus)
+    if (grid > 1 && posts) {
+        const size_t per = (size_t)kNewtonPostEpochs * (2 * e->num_cus) * 2;   // (slots are indexed with the launch's grid <= 2 num_cus)
         A.posts = e->d_newton_posts + (e->newton_post_launches & 1) * per;
         A.posts_other = e->d_newton_posts + ((e->newton_post_launches + 1) & 1) * per;
         e->newton_post_launches++;
