@@ -299,6 +299,16 @@ int iqhip_upload_partial(iqhip_engine *e, uint64_t key, const double *partial_lh
 int iqhip_timing_enable(iqhip_engine *e, int on);
 int iqhip_timing_read(iqhip_engine *e, double *avg_ms, int64_t *launches, int reset);
 
+/* Debugging aid, no reference counterpart: a PLANNING-ONLY engine makes no HIP call and owns no device memory (its
+ * vectors are distinct fake addresses).  iqhip_debug_plan turns an op list into the device descriptors exactly as
+ * iqhip_update_partials would (key -> slab map, canonical child order, staging, LDS chunks, K2 table slots, look-ahead
+ * sentinels) and validates the kernels' contract on them: every pointer of every descriptor, used or not, is a live
+ * allocation of the right kind (the traversal kernels request op k+1's inputs unconditionally).  The same check runs on
+ * a real engine before every plan upload when IQHIP_CHECK_PLAN=1.  Every other entry point fails on a planner. */
+int iqhip_debug_create_planner(iqhip_engine **out, int nstates /* 4, 20, 64 */, int ncat, int64_t nptn, int ntaxa,
+                               int num_cus, int state_unknown, int nclass);
+int iqhip_debug_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,7 @@
  *
  * What X must provide (all static):
  *   typedef ... Tree, Node, Neighbor;
- *   Node *node(Neighbor *);  double length(Neighbor *);
+ *   Node *node(Neighbor *);  double length(Neighbor *);  void setLength(Neighbor *, double);
  *   bool isLeaf(Node *);  int degree(Node *);  int leafId(Node *);          // leafId = row of the alignment
  *   int numNeighbors(Node *);  Neighbor *neighborAt(Node *, int);  Neighbor *findNeighbor(Node *at, Node *to);
  *   int &computed(Neighbor *);            // partial_lh_computed (bit 0)
@@ -348,7 +348,12 @@ inline double computeLikelihoodFromBuffer(typename X::Tree *tree) {
 }
 
 /* optimizeOneBranch's `optx = minimizeNewton(...)` (phylotree.cpp:2148-2192, optimization.cpp:388-465) as ONE engine
- * call: pending node updates of both ends + theta + the whole solve.  current_it / current_it_back name the branch. */
+ * call: pending node updates of both ends + theta + the whole solve.  current_it / current_it_back name the branch.
+ * Like the reference's loop, the call leaves the branch at the LAST EVALUATED length: computeFuncDerv
+ * (phylotree.cpp:2135-2137) stores every trial length into current_it / current_it_back, and on every return path of
+ * minimizeNewton the value returned is the point evaluated last (`return rts_old` is taken before the new rts is
+ * evaluated; the `xl == rts` / `temp == rts` exits return a point that equals it to the last bit or ulp).  The
+ * diverged-Newton test that follows in optimizeOneBranch (phylotree.cpp:2167-2176) evaluates opt_lh at that length. */
 template <class X>
 inline double minimizeNewtonOnBranch(typename X::Tree *tree, double current_len, int max_steps, int *nsteps = 0,
                                      Plan<X> *plan_out = 0) {
@@ -366,6 +371,8 @@ inline double minimizeNewtonOnBranch(typename X::Tree *tree, double current_len,
     const double optx = X::optimizeBranch(tree, plan, branchEnd<X>(node_branch), branchEnd<X>(dad_branch), current_len,
                                           max_steps, &sum_scale[0], &steps);
     applyScaleFactors<X>(plan, &sum_scale[0]);
+    X::setLength(X::currentIt(tree), optx);
+    X::setLength(X::currentItBack(tree), optx);
     if (nsteps) *nsteps = steps;
     if (plan_out) *plan_out = plan;
     return optx;

@@ -23,6 +23,7 @@
 // computeBayesianBranchLength) calls hipFetchPartialLh() first.
 #include "phylotree.h"
 #include "model/modelfactory.h"
+#include "model/modelmixture.h"  // ModelMixture::prop (as phylokernelmixture.h does)
 #include "iqhip.h"
 
 #define IQHIP_CHECK(call)                                                     \
@@ -32,7 +33,7 @@
 
 static inline uint64_t hipKey(PhyloNeighbor *nei) { return (uint64_t)(uintptr_t)nei->get_partial_lh(); }
 
-// multi-GPU: `-hip-devices 0,1,..,7` (params->hip_devices) makes ONE engine over several GPUs of this process
+// multi-GPU: `-hipdevs 0,1,..,7` (params->hip_devices) makes ONE engine over several GPUs of this process
 // (iqhip_create_sharded: patterns sharded, one RCCL all-reduce per evaluation inside the engine); nothing else in
 // this file changes
 static int hipCreateEngine(iqhip_engine **e, Params *params, int nstates, int ncat, size_t nptn, int ntaxa) {
@@ -137,6 +138,7 @@ struct HipPolicy : iqhip_adapter::EngineCalls<HipPolicy, PhyloTree> {
     typedef PhyloNeighbor Neighbor;
     static Node *node(Neighbor *nb) { return (PhyloNode *)nb->node; }
     static double length(Neighbor *nb) { return nb->length; }
+    static void setLength(Neighbor *nb, double len) { nb->length = len; }
     static bool isLeaf(Node *n) { return n->isLeaf(); }
     static int degree(Node *n) { return n->degree(); }
     static int leafId(Node *n) { return n->id; }

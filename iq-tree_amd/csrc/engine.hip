@@ -43,6 +43,81 @@ template <typename T>
 static hipError_t dmalloc(T **p, size_t count) {
     return hipMalloc((void **)p, count * sizeof(T));
 }
+// a planning-only engine has no device: every entry point that would touch one fails here ("invalid device ordinal")
+static hipError_t use_device(const iqhip_engine *e) { return e->planner ? hipErrorInvalidDevice : hipSetDevice(e->device); }
+// planning-only engines: a distinct, 256-byte aligned address range that is never dereferenced
+template <typename T>
+static T *fake_alloc(iqhip_engine *e, size_t count) {
+    const uint64_t a = e->fake_next;
+    e->fake_next += (count * sizeof(T) + 255) / 256 * 256 + 256;
+    return reinterpret_cast<T *>(a);
+}
+
+// everything about an engine that follows from its shape, the CU count (e->num_cus, set by the caller) and the
+// environment switches -- no HIP call, so that the planning-only engine of iqhip_debug_create_planner shares it
+static void configure_engine(iqhip_engine *e, int device, int nstates, int nstates_user, int ncat, int64_t nptn, int ntaxa) {
+    e->device = device;
+    e->n = nstates;
+    e->n_user = nstates_user;
+    e->embed2 = nstates_user == 2;
+    e->ncat = ncat;
+    e->ntaxa = ntaxa;
+    e->nptn = nptn;
+    e->mfma = nstates != 4;
+    e->mfma_pipelined_ok = ((nstates == 20 && (ncat == 4 || ncat == 1)) || (nstates == 64 && ncat == 1)) &&
+                           !getenv("IQHIP_MFMA_V1");
+    e->mfma_pipelined = e->mfma_pipelined_ok;
+    e->tile = e->mfma ? 16 : 64;
+    e->block = nstates * ncat;
+    e->nptn_pad = round_up(nptn, 64);
+    e->ntiles = e->nptn_pad / e->tile;
+
+    if (const char *ab = getenv("IQHIP_ABLATE")) e->ablate = atoi(ab);
+    if (const char *cp = getenv("IQHIP_CHECK_PLAN")) e->check_plans = atoi(cp) != 0;
+    if (const char *h = getenv("IQHIP_HOLD")) e->use_hold = atoi(h) != 0;
+    if (const char *h = getenv("IQHIP_HOLD_LDS")) e->hold_lds = atoi(h) != 0;
+    if (const char *h = getenv("IQHIP_NEWTON_POSTS")) e->newton_posts = atoi(h) != 0;
+    if (const char *h = getenv("IQHIP_SMALL_PLANS")) e->small_plans = atoi(h) != 0;
+    if (const char *h = getenv("IQHIP_MIXED_TOP")) e->mixed_top = atoi(h) != 0;
+    if (const char *f = getenv("IQHIP_FOLD")) e->fold_reduce = atoi(f) != 0;
+    if (const char *f = getenv("IQHIP_POLL")) e->poll_result = atoi(f) != 0;
+    if (const char *sp = getenv("IQHIP_SPLIT")) e->split_target = atoi(sp);
+    if (const char *kb = getenv("IQHIP_LDS_KB")) {
+        int v = atoi(kb);
+        if (v >= 8 && v <= 150) e->lds_budget_bytes = v * 1024;
+    }
+    // K2 tables for leaf children: on for 64 states (matrix-pipe bound: 0.50 -> 0.40 ms per traversal at 50 x 20k);
+    // off for 20 states, where the traversal is not bound by the MFMA count (1.08 vs 1.11 ms at 100 x 50k) and a model
+    // change would cost a table rebuild per evaluation.  IQHIP_LEAF_TABLES=0|1 overrides (tests run both).
+    e->leaf_tables = e->mfma_pipelined_ok && nstates == 64;
+    if (const char *lt = getenv("IQHIP_LEAF_TABLES")) e->leaf_tables = e->mfma_pipelined_ok && atoi(lt) != 0;
+    if (const char *wg = getenv("IQHIP_WG")) {
+        int v = atoi(wg);
+        if (v == 64 || v == 128 || v == 256) e->wg_size = v;
+    }
+
+    // 4-state kernel, two lanes per pattern: twice the waves with half the register state each, as long as
+    // they all fit the chip at once (2 waves per SIMD).  Measured, GTR+G4 50 taxa: 10k..65k patterns 0.116..
+    // 0.130 ms -> 0.086..0.114 ms; 80k patterns 0.145 -> 0.191 ms (second round).  IQHIP_LANE_SPLIT=1|2 overrides
+    if (!e->mfma && ncat % 2 == 0) {
+        e->lane_split = (2 * (e->nptn_pad / 64) <= 2 * (int64_t)e->num_cus * 4) ? 2 : 1;
+        if (const char *ls = getenv("IQHIP_LANE_SPLIT")) e->lane_split = (atoi(ls) == 2) ? 2 : 1;
+    }
+    // 20 states x 4 categories on a small alignment: one wave per (tile, category) while that is at most one wave
+    // per SIMD (100 taxa: 500 patterns 0.221 -> 0.111 ms, 2000 patterns 0.219 -> 0.145 ms, 8000 patterns 0.247 -> 0.267 ms)
+    if (e->mfma_pipelined_ok && e->n == 20 && e->ncat == 4) {
+        e->cat_split = 4 * e->ntiles <= (int64_t)e->num_cus * 4;
+        if (const char *cs = getenv("IQHIP_CAT_SPLIT")) e->cat_split = atoi(cs) != 0;
+        // the dependent top stage of a staged plan with two waves per tile (two categories each, three waves per SIMD) while the
+        // alignment has only a few tiles per SIMD: 3125 tiles on 2048 two-wave slots took two rounds of full chains (-1.8 %)
+        e->top_cs2 = !e->cat_split && e->ntiles < 6 * (int64_t)e->num_cus * 4;
+        if (const char *cs = getenv("IQHIP_TOP_CS2")) e->top_cs2 = atoi(cs) != 0;
+    }
+    if (e->mfma_pipelined_ok && e->n == 64 && e->ncat == 1) {
+        e->row_split = 4 * e->ntiles <= (int64_t)e->num_cus * 4;
+        if (const char *rs = getenv("IQHIP_ROW_SPLIT")) e->row_split = atoi(rs) != 0;
+    }
+}
 
 extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int ncat, int64_t nptn,
                             int ntaxa) {
@@ -73,21 +148,12 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     HIPCHK(hipSetDevice(device));
 
     iqhip_engine *e = new iqhip_engine();
-    e->device = device;
-    e->n = nstates;
-    e->n_user = nstates_user;
-    e->embed2 = nstates_user == 2;
-    e->ncat = ncat;
-    e->ntaxa = ntaxa;
-    e->nptn = nptn;
-    e->mfma = nstates != 4;
-    e->mfma_pipelined_ok = ((nstates == 20 && (ncat == 4 || ncat == 1)) || (nstates == 64 && ncat == 1)) &&
-                           !getenv("IQHIP_MFMA_V1");
-    e->mfma_pipelined = e->mfma_pipelined_ok;
-    e->tile = e->mfma ? 16 : 64;
-    e->block = nstates * ncat;
-    e->nptn_pad = round_up(nptn, 64);
-    e->ntiles = e->nptn_pad / e->tile;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+            e->num_cus = cus;
+    }
+    configure_engine(e, device, nstates, nstates_user, ncat, nptn, ntaxa);
 
     hipError_t s = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (s != hipSuccess) {
@@ -95,29 +161,6 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
         return fail(IQHIP_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(s));
     }
     e->own_stream = true;
-    if (const char *ab = getenv("IQHIP_ABLATE")) e->ablate = atoi(ab);
-    if (const char *h = getenv("IQHIP_HOLD")) e->use_hold = atoi(h) != 0;
-    if (const char *h = getenv("IQHIP_HOLD_LDS")) e->hold_lds = atoi(h) != 0;
-    if (const char *h = getenv("IQHIP_NEWTON_POSTS")) e->newton_posts = atoi(h) != 0;
-    if (const char *h = getenv("IQHIP_SMALL_PLANS")) e->small_plans = atoi(h) != 0;
-    if (const char *h = getenv("IQHIP_MIXED_TOP")) e->mixed_top = atoi(h) != 0;
-    if (const char *f = getenv("IQHIP_FOLD")) e->fold_reduce = atoi(f) != 0;
-    if (const char *f = getenv("IQHIP_POLL")) e->poll_result = atoi(f) != 0;
-    if (const char *sp = getenv("IQHIP_SPLIT")) e->split_target = atoi(sp);
-    if (const char *kb = getenv("IQHIP_LDS_KB")) {
-        int v = atoi(kb);
-        if (v >= 8 && v <= 150) e->lds_budget_bytes = v * 1024;
-    }
-    // K2 tables for leaf children: on for 64 states (matrix-pipe bound: 0.50 -> 0.40 ms per traversal at 50 x 20k);
-    // off for 20 states, where the traversal is not bound by the MFMA count (1.08 vs 1.11 ms at 100 x 50k) and a model
-    // change would cost a table rebuild per evaluation.  IQHIP_LEAF_TABLES=0|1 overrides (tests run both).
-    e->leaf_tables = e->mfma_pipelined_ok && nstates == 64;
-    if (const char *lt = getenv("IQHIP_LEAF_TABLES")) e->leaf_tables = e->mfma_pipelined_ok && atoi(lt) != 0;
-    if (const char *wg = getenv("IQHIP_WG")) {
-        int v = atoi(wg);
-        if (v == 64 || v == 128 || v == 256) e->wg_size = v;
-    }
-
     const size_t P = (size_t)e->nptn_pad;
     bool ok = dmalloc(&e->d_states, (size_t)ntaxa * P) == hipSuccess &&
               dmalloc(&e->d_freq, P) == hipSuccess && dmalloc(&e->d_invar, P) == hipSuccess &&
@@ -144,9 +187,6 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     hipMemsetAsync(e->dummy.plh, 0, P * e->block * sizeof(double), e->stream);
     hipMemsetAsync(e->dummy.sc, 0, P * sizeof(int16_t), e->stream);
     {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
-            e->num_cus = cus;
         ok = dmalloc(&e->d_newton_partials, (size_t)4 * e->num_cus) == hipSuccess &&
              dmalloc(&e->d_newton_barrier, 2) == hipSuccess && dmalloc(&e->d_fold_ticket, 4) == hipSuccess &&
              dmalloc(&e->d_newton_posts, (size_t)2 * kNewtonPostEpochs * (2 * e->num_cus) * 2) == hipSuccess &&
@@ -159,27 +199,6 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
             iqhip_destroy(e);
             return fail(IQHIP_ERR_NOMEM, "iqhip_create: device allocation failed");
         }
-    }
-    // 4-state kernel, two lanes per pattern: twice the waves with half the register state each, as long as
-    // they all fit the chip at once (2 waves per SIMD).  Measured, GTR+G4 50 taxa: 10k..65k patterns 0.116..
-    // 0.130 ms -> 0.086..0.114 ms; 80k patterns 0.145 -> 0.191 ms (second round).  IQHIP_LANE_SPLIT=1|2 overrides
-    if (!e->mfma && ncat % 2 == 0) {
-        e->lane_split = (2 * (e->nptn_pad / 64) <= 2 * (int64_t)e->num_cus * 4) ? 2 : 1;
-        if (const char *ls = getenv("IQHIP_LANE_SPLIT")) e->lane_split = (atoi(ls) == 2) ? 2 : 1;
-    }
-    // 20 states x 4 categories on a small alignment: one wave per (tile, category) while that is at most one wave
-    // per SIMD (100 taxa: 500 patterns 0.221 -> 0.111 ms, 2000 patterns 0.219 -> 0.145 ms, 8000 patterns 0.247 -> 0.267 ms)
-    if (e->mfma_pipelined_ok && e->n == 20 && e->ncat == 4) {
-        e->cat_split = 4 * e->ntiles <= (int64_t)e->num_cus * 4;
-        if (const char *cs = getenv("IQHIP_CAT_SPLIT")) e->cat_split = atoi(cs) != 0;
-        // the dependent top stage of a staged plan with two waves per tile (two categories each, three waves per SIMD) while the
-        // alignment has only a few tiles per SIMD: 3125 tiles on 2048 two-wave slots took two rounds of full chains (-1.8 %)
-        e->top_cs2 = !e->cat_split && e->ntiles < 6 * (int64_t)e->num_cus * 4;
-        if (const char *cs = getenv("IQHIP_TOP_CS2")) e->top_cs2 = atoi(cs) != 0;
-    }
-    if (e->mfma_pipelined_ok && e->n == 64 && e->ncat == 1) {
-        e->row_split = 4 * e->ntiles <= (int64_t)e->num_cus * 4;
-        if (const char *rs = getenv("IQHIP_ROW_SPLIT")) e->row_split = atoi(rs) != 0;
     }
     e->d_result = e->d_result_own;
     hipMemsetAsync(e->d_theta, 0, P * e->block * sizeof(double), e->stream);
@@ -198,7 +217,12 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
         delete e;
         return;
     }
-    hipSetDevice(e->device);
+    if (e->planner) {
+        free(e->h_ops);
+        delete e;
+        return;
+    }
+    use_device(e);
     if (e->stream) hipStreamSynchronize(e->stream);
     comm_destroy(e);
     if (e->d_result_dev) hipFree(e->d_result_dev);
@@ -230,7 +254,7 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
 extern "C" int iqhip_set_stream(iqhip_engine *e, void *hip_stream) {
     if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
     if (!e->shards.empty()) return fail(IQHIP_ERR_UNSUPPORTED, "a sharded engine runs on its shards' own streams");
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->own_stream) hipStreamDestroy(e->stream);
     e->stream = (hipStream_t)hip_stream;
@@ -249,6 +273,13 @@ static int new_slab(iqhip_engine *e, int *idx) {
     }
     Slab s;
     const size_t P = (size_t)e->nptn_pad;
+    if (e->planner) {
+        s.plh = fake_alloc<double>(e, P * e->block);
+        s.sc = fake_alloc<int16_t>(e, P);
+        e->slabs.push_back(s);
+        *idx = (int)e->slabs.size() - 1;
+        return IQHIP_OK;
+    }
     if (dmalloc(&s.plh, P * e->block) != hipSuccess) return fail(IQHIP_ERR_NOMEM, "slab alloc");
     if (dmalloc(&s.sc, P) != hipSuccess) {
         hipFree(s.plh);
@@ -279,7 +310,7 @@ static int slab_for_key(iqhip_engine *e, uint64_t key, bool create, int *idx) {
 extern "C" int iqhip_reserve(iqhip_engine *e, int nvectors) {
     if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
     if (!e->shards.empty()) return sharded::reserve(e, nvectors);
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     int have = (int)e->slabs.size();
     for (int i = have; i < nvectors; i++) {
         int idx;
@@ -325,7 +356,7 @@ extern "C" int iqhip_rekey(iqhip_engine *e, uint64_t old_key, uint64_t new_key) 
 extern "C" int iqhip_set_ptn_freq(iqhip_engine *e, const double *ptn_freq) {
     if (!e || !ptn_freq) return fail(IQHIP_ERR_INVALID, "null argument");
     if (!e->shards.empty()) return sharded::set_ptn_array(e, ptn_freq, false);
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     std::vector<double> tmp((size_t)e->nptn_pad, 0.0);
     memcpy(tmp.data(), ptn_freq, sizeof(double) * (size_t)e->nptn);
     HIPCHK(hipMemcpyAsync(e->d_freq, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice,
@@ -337,7 +368,7 @@ extern "C" int iqhip_set_ptn_freq(iqhip_engine *e, const double *ptn_freq) {
 extern "C" int iqhip_set_ptn_invar(iqhip_engine *e, const double *ptn_invar) {
     if (!e || !ptn_invar) return fail(IQHIP_ERR_INVALID, "null argument");
     if (!e->shards.empty()) return sharded::set_ptn_array(e, ptn_invar, true);
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     std::vector<double> tmp((size_t)e->nptn_pad, 0.0);
     memcpy(tmp.data(), ptn_invar, sizeof(double) * (size_t)e->nptn);
     HIPCHK(hipMemcpyAsync(e->d_invar, tmp.data(), tmp.size() * sizeof(double),
@@ -353,7 +384,7 @@ extern "C" int iqhip_set_alignment(iqhip_engine *e, const uint8_t *states, const
     if (!e->model_set)
         return fail(IQHIP_ERR_INVALID,
                     "iqhip_set_alignment: call iqhip_set_model first (needs state_unknown)");
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     const size_t P = (size_t)e->nptn_pad, N = (size_t)e->nptn;
     // (binary data: padding patterns and missing characters are the ambiguity set {0, 1}, never the kernels' unknown)
     std::vector<uint8_t> tmp((size_t)e->ntaxa * P, (uint8_t)(e->embed2 ? 6 : e->state_unknown));
@@ -413,7 +444,7 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
     if (e->n == 4) {
         const bool want_mfma = nclass > 1;
         if (want_mfma != e->mfma) {
-            HIPCHK(hipSetDevice(e->device));
+            HIPCHK(use_device(e));
             HIPCHK(hipStreamSynchronize(e->stream));
             e->mfma = want_mfma;
             if (want_mfma) { e->lane_split_valu = e->lane_split; e->lane_split = 1; }  // (a VALU-kernel notion)
@@ -423,6 +454,10 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
             e->uploaded_plan.clear();
             e->last_plan_version = 0;
             e->theta_valid = false;
+            // k_newton's posted exchange resets, per launch, the slots its OWN grid used in the other parity; the grid
+            // follows ntiles, so after a layout change start both parities from the all-ones state again
+            HIPCHK(hipMemsetAsync(e->d_newton_posts, 0xFF, (size_t)2 * kNewtonPostEpochs * (2 * e->num_cus) * 2 * sizeof(double), e->stream));
+            e->newton_post_launches = 0;
         }
     }
     std::vector<int> cls(e->ncat, 0);
@@ -433,7 +468,7 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
             cls[c] = cat_class[c];
         }
     }
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     const int n = e->n, C = e->ncat;
     HIPCHK(hipStreamSynchronize(e->stream));  // previous work may still read the old model
     // One device block, one copy per model change (the model optimisers call this once per evaluation):
@@ -598,8 +633,17 @@ extern "C" int iqhip_set_mixture_model(iqhip_engine *e, int nclass, const int32_
 // ---------------------------------------------------------------------------------------
 static int ensure_plan_capacity(iqhip_engine *e, int nops) {
     if (nops <= e->ops_cap) return IQHIP_OK;
-    HIPCHK(hipStreamSynchronize(e->stream));
     int cap = std::max(64, nops * 2);
+    if (e->planner) {
+        free(e->h_ops);
+        e->h_ops = static_cast<DevOp *>(calloc((size_t)cap, sizeof(DevOp)));
+        if (!e->h_ops) return fail(IQHIP_ERR_NOMEM, "plan staging");
+        e->d_ops = fake_alloc<DevOp>(e, (size_t)cap);
+        e->ops_cap = cap;
+        e->uploaded_plan.clear();
+        return IQHIP_OK;
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
     if (e->d_ops) hipFree(e->d_ops);
     if (e->h_ops) hipHostFree(e->h_ops);
     e->d_ops = nullptr; e->h_ops = nullptr; e->ops_cap = 0;
@@ -626,7 +670,7 @@ static int check_ready(iqhip_engine *e) {
     if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
     if (!e->model_set || !e->aln_set)
         return fail(IQHIP_ERR_INVALID, "engine needs iqhip_set_model and iqhip_set_alignment first");
-    hipError_t s = hipSetDevice(e->device);
+    hipError_t s = use_device(e);
     if (s != hipSuccess) return fail(IQHIP_ERR_HIP, hipGetErrorString(s));
     return IQHIP_OK;
 }
@@ -648,6 +692,77 @@ static int resolve_child(iqhip_engine *e, uint64_t key, int32_t leaf, int prev_d
     *plh = e->slabs[idx].plh;
     *sc = e->slabs[idx].sc;
     *kind = (idx == prev_dst) ? CHILD_PREV : CHILD_LOAD;
+    return IQHIP_OK;
+}
+
+// The kernels' contract on a plan, checked on the host before the descriptors go to the device (IQHIP_CHECK_PLAN=1; always
+// for a planning-only engine).  The traversal kernels issue the requests of op k+1 unconditionally while op k computes
+// (streamed child, its counters, leaf state rows, K2 table rows), so EVERY pointer of EVERY descriptor -- the look-ahead
+// sentinels behind the last op included -- must be a dereferenceable address of the right kind even when the op does not
+// use it: a null tabL / tabR of a non-leaf child was a GPU memory fault in round 2 that this check finds without a GPU.
+static int check_plan(iqhip_engine *e, int nops, int nsentinels) {
+    std::unordered_set<const void *> vecs, scs;
+    for (const Slab &sl : e->slabs) { vecs.insert(sl.plh); scs.insert(sl.sc); }
+    vecs.insert(e->dummy.plh);
+    scs.insert(e->dummy.sc);
+    const size_t per = (e->mfma && e->mfma_pipelined) ? leaf_table_doubles(e) : 0;
+    char msg[256];
+    auto bad = [&](int k, const char *what) {
+        snprintf(msg, sizeof msg, "plan check: op %d of %d (+%d sentinels): %s", k, nops, nsentinels, what);
+        return fail(IQHIP_ERR_INVALID, msg);
+    };
+    auto state_row = [&](const uint8_t *p) {
+        if (!p || !e->d_states || p < e->d_states) return false;
+        const size_t off = (size_t)(p - e->d_states);
+        return off % (size_t)e->nptn_pad == 0 && off / (size_t)e->nptn_pad < (size_t)e->ntaxa;
+    };
+    auto table = [&](const double *p) {
+        if (e->plan_nleaf_tabs == 0 && !e->d_leaf_tab) return p == nullptr;  // kernel variant without tables
+        if (!p || !e->d_leaf_tab || p < e->d_leaf_tab || per == 0) return false;
+        const size_t off = (size_t)(p - e->d_leaf_tab);
+        return off % per == 0 && off / per < e->leaf_tab_slots;
+    };
+    for (int k = 0; k < nops + nsentinels; k++) {
+        const DevOp &d = e->h_ops[k];
+        if (!vecs.count(d.dst) || d.dst == nullptr) return bad(k, "dst is not a vector slab");
+        if (!scs.count(d.dst_sc)) return bad(k, "dst_sc is not a counter slab");
+        if (!vecs.count(d.pf)) return bad(k, "pf (streamed child) is not a vector slab / the dummy slab");
+        if (!scs.count(d.pf_sc)) return bad(k, "pf_sc is not a counter slab / the dummy");
+        if (!vecs.count(d.ld)) return bad(k, "ld (second memory child) is not a vector slab / the dummy slab");
+        if (!scs.count(d.ld_sc)) return bad(k, "ld_sc is not a counter slab / the dummy");
+        if (!state_row(d.sl) || !state_row(d.sr)) return bad(k, "sl / sr is not a row of the state matrix");
+        if (!table(d.tabL) || !table(d.tabR)) return bad(k, "tabL / tabR is not a K2 table slot");
+        if (k >= nops) continue;  // sentinels: pointers only
+        if (d.dst == e->dummy.plh || d.dst_sc == e->dummy.sc) return bad(k, "a real op writes the dummy slab");
+        const bool lk = d.left_kind == CHILD_LEAF || d.left_kind == CHILD_PF || d.left_kind == CHILD_HOLD ||
+                        (d.left_kind == CHILD_LOAD && e->mfma && !e->mfma_pipelined);
+        const bool rk = d.right_kind == CHILD_LEAF || d.right_kind == CHILD_PREV || d.right_kind == CHILD_LOAD;
+        if (!lk || !rk) return bad(k, "child kinds are not in canonical form");
+        if (d.left_kind == CHILD_PF && (d.pf == e->dummy.plh || !(d.real_mask & 1))) return bad(k, "streamed child without a real vector");
+        if (d.left_kind != CHILD_PF && !(e->mfma && !e->mfma_pipelined) && (d.real_mask & 1)) return bad(k, "real_mask set without a streamed child");
+        if (d.right_kind == CHILD_LOAD && d.ld == e->dummy.plh) return bad(k, "second memory child without a real vector");
+        if (d.dst == d.pf || d.dst == d.ld) return bad(k, "op writes one of its own children");
+        if (!(d.left_len >= 0.0) || !(d.right_len >= 0.0)) return bad(k, "negative or NaN branch length");
+        if (d.out_row < 0 || d.out_row >= nops) return bad(k, "out_row outside the caller's op list");
+        if (d.lds_left < 0 || d.lds_right < 0 || d.lds_left > e->plan_lds_doubles || d.lds_right > e->plan_lds_doubles)
+            return bad(k, "LDS region outside the launch's allocation");
+        if (d.sl_slot < 0 || d.sr_slot < 0 || d.sl_slot >= e->plan_state_slots || d.sr_slot >= e->plan_state_slots)
+            return bad(k, "leaf-state slot outside the launch's allocation");
+        if (d.chunk_nops < 0 || k + d.chunk_nops > nops) return bad(k, "LDS chunk runs past the plan");
+    }
+    // chunks tile the plan; the segment table stays inside it
+    for (int k = 0; k < nops;) {
+        if (e->h_ops[k].chunk_nops <= 0) return bad(k, "op is not covered by an LDS chunk");
+        k += e->h_ops[k].chunk_nops;
+    }
+    const int *tab = reinterpret_cast<const int *>(e->h_ops + e->plan_table_off);
+    int covered = 0;
+    for (int u = 0; u <= e->plan_nunits; u++) {
+        const int b = tab[2 * u], n = tab[2 * u + 1];
+        if (b < 0 || n < 0 || b + n > nops) return bad(b, "segment outside the plan");
+        covered += n;
+    }
+    if (covered != nops) return bad(nops, "segments do not cover the plan exactly once");
     return IQHIP_OK;
 }
 
@@ -975,12 +1090,16 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         }
         const size_t need = (size_t)e->ntaxa + (size_t)noverflow;
         if (need > e->leaf_tab_slots) {
-            HIPCHK(hipStreamSynchronize(e->stream));
-            if (e->d_leaf_tab) hipFree(e->d_leaf_tab);
-            e->d_leaf_tab = nullptr;
-            e->leaf_tab_slots = 0;
             const size_t slots = need + 16;
-            HIPCHK(dmalloc(&e->d_leaf_tab, slots * per));
+            if (e->planner) {
+                e->d_leaf_tab = fake_alloc<double>(e, slots * per);
+            } else {
+                HIPCHK(hipStreamSynchronize(e->stream));
+                if (e->d_leaf_tab) hipFree(e->d_leaf_tab);
+                e->d_leaf_tab = nullptr;
+                e->leaf_tab_slots = 0;
+                HIPCHK(dmalloc(&e->d_leaf_tab, slots * per));
+            }
             e->leaf_tab_slots = slots;
             e->uploaded_plan.clear();
             // a new buffer holds no tables: everything this plan uses is dirty
@@ -1088,6 +1207,19 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
     const bool small_kernel = !e->mfma || (e->mfma_pipelined && e->n == 20 && !e->leaf_tables && e->plan_nleaf_tabs == 0);
     e->plan_small = e->small_plans && small_kernel && !explicit_segs && units.empty() && nops > 0 && nops + kSentinels <= kSmallPlanOps;
     e->plan_small_nops = nops;
+    if (e->planner) {   // negative tests: break one descriptor the way round 2's fault did
+        const char *br = getenv("IQHIP_DEBUG_BREAK_PLAN");
+        if (br && nops > 0) {
+            if (!strcmp(br, "tab")) e->h_ops[nops - 1].tabL = nullptr;
+            else if (!strcmp(br, "sentinel")) e->h_ops[nops + kSentinels - 1].pf = nullptr;
+            else if (!strcmp(br, "states")) e->h_ops[0].sr = nullptr;
+        }
+    }
+    if (e->check_plans && !e->ablate) {
+        rc = check_plan(e, nops, kSentinels);
+        if (rc) { e->last_plan_version = 0; e->uploaded_plan.clear(); return rc; }
+    }
+    if (e->planner) return IQHIP_OK;   // (nothing to upload to)
     if (e->plan_small) {
         e->uploaded_plan.assign((const char *)e->h_ops, (const char *)e->h_ops + nbytes);   // (what d_ops would hold)
         return IQHIP_OK;
@@ -1434,20 +1566,20 @@ int eng_newton_begin(iqhip_engine *e, double xguess, double x1, double x2, doubl
     return IQHIP_OK;
 }
 int eng_newton_eval_enqueue(iqhip_engine *e) {
-    if (hipSetDevice(e->device) != hipSuccess) return set_error(IQHIP_ERR_HIP, "hipSetDevice");
+    if (use_device(e) != hipSuccess) return set_error(IQHIP_ERR_HIP, "hipSetDevice");
     const int nwaves = (int)e->ntiles;
     if (launch_derv_at_state(e, nwaves) != hipSuccess || launch_reduce(e, 0, 2, nwaves) != hipSuccess)
         return set_error(IQHIP_ERR_HIP, "Newton chain: launch failed");
     return IQHIP_OK;
 }
 int eng_newton_update_enqueue(iqhip_engine *e) {
-    if (hipSetDevice(e->device) != hipSuccess) return set_error(IQHIP_ERR_HIP, "hipSetDevice");
+    if (use_device(e) != hipSuccess) return set_error(IQHIP_ERR_HIP, "hipSetDevice");
     if (launch_newton_state_update(e) != hipSuccess) return set_error(IQHIP_ERR_HIP, "Newton chain: launch failed");
     return IQHIP_OK;
 }
 
 int newton_state_read(iqhip_engine *e) {
-    if (hipSetDevice(e->device) != hipSuccess) return set_error(IQHIP_ERR_HIP, "hipSetDevice");
+    if (use_device(e) != hipSuccess) return set_error(IQHIP_ERR_HIP, "hipSetDevice");
     if (hipMemcpyAsync(e->h_nstate, e->d_nstate, sizeof(NewtonState), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
         hipStreamSynchronize(e->stream) != hipSuccess)
         return set_error(IQHIP_ERR_HIP, "Newton chain: state read failed");
@@ -1833,7 +1965,7 @@ extern "C" int iqhip_bind_result_buffer(iqhip_engine *e, void *device_ptr, int c
     if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
     if (!e->shards.empty() || e->comm)
         return fail(IQHIP_ERR_UNSUPPORTED, "an engine with a communicator reduces in its own device result vector");
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (!device_ptr) {
         e->d_result = e->d_result_own;
@@ -1853,7 +1985,7 @@ extern "C" int iqhip_result_read(iqhip_engine *e, double *out, int ndoubles) {
         return fail(IQHIP_ERR_UNSUPPORTED, "a sharded engine reduces its results itself: use the synchronous calls");
     if (!e || !out || ndoubles < 0 || ndoubles > e->result_cap)
         return fail(IQHIP_ERR_INVALID, "iqhip_result_read: bad arguments");
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     int rc = read_result(e, ndoubles);
     if (rc) return rc;
     memcpy(out, e->h_result, sizeof(double) * ndoubles);
@@ -1863,7 +1995,7 @@ extern "C" int iqhip_result_read(iqhip_engine *e, double *out, int ndoubles) {
 extern "C" int iqhip_synchronize(iqhip_engine *e) {
     if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
     if (!e->shards.empty()) return sharded::synchronize(e);
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->staging_busy = false;
     return IQHIP_OK;
@@ -1897,7 +2029,7 @@ static int fetch_vec(iqhip_engine *e, const double *dptr, double *out) {
 extern "C" int iqhip_fetch_partial(iqhip_engine *e, uint64_t key, double *out) {
     if (!e || !out) return fail(IQHIP_ERR_INVALID, "null argument");
     if (!e->shards.empty()) return sharded::fetch_vec(e, key, false, out);
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     int idx;
     int rc = slab_for_key(e, key, false, &idx);
     if (rc) return rc;
@@ -1907,14 +2039,14 @@ extern "C" int iqhip_fetch_partial(iqhip_engine *e, uint64_t key, double *out) {
 extern "C" int iqhip_fetch_theta(iqhip_engine *e, double *out) {
     if (!e || !out) return fail(IQHIP_ERR_INVALID, "null argument");
     if (!e->shards.empty()) return sharded::fetch_vec(e, 0, true, out);
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     return fetch_vec(e, e->d_theta, out);
 }
 
 extern "C" int iqhip_fetch_scale_num(iqhip_engine *e, uint64_t key, int16_t *out) {
     if (!e || !out) return fail(IQHIP_ERR_INVALID, "null argument");
     if (!e->shards.empty()) return sharded::fetch_scale_num(e, key, out);
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     int idx;
     int rc = slab_for_key(e, key, false, &idx);
     if (rc) return rc;
@@ -1926,7 +2058,7 @@ extern "C" int iqhip_fetch_scale_num(iqhip_engine *e, uint64_t key, int16_t *out
 extern "C" int iqhip_fetch_pattern_lh(iqhip_engine *e, double *out) {
     if (!e || !out) return fail(IQHIP_ERR_INVALID, "null argument");
     if (!e->shards.empty()) return sharded::fetch_pattern_lh(e, out, 0, iqhip_branch_end{0, -1, 0}, iqhip_branch_end{0, -1, 0});
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(out, e->d_pattern_lh, sizeof(double) * (size_t)e->nptn, hipMemcpyDeviceToHost));
     if (e->n_unobs > 0) {  // phylokernel.h:1013-1014: observed patterns only
@@ -1956,7 +2088,7 @@ static int scaled_pattern_lh(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_e
 extern "C" int iqhip_fetch_pattern_lh_scaled(iqhip_engine *e, iqhip_branch_end a, iqhip_branch_end b, double *out) {
     if (!e || !out) return fail(IQHIP_ERR_INVALID, "null argument");
     if (!e->shards.empty()) return sharded::fetch_pattern_lh(e, out, 1, a, b);
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     int rc = scaled_pattern_lh(e, a, b);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(out, e->d_ptn_scaled, sizeof(double) * (size_t)e->nptn, hipMemcpyDeviceToHost, e->stream));
@@ -1969,7 +2101,7 @@ extern "C" int iqhip_pattern_lh_cat(iqhip_engine *e, double len, double *out) {
     if (!e->shards.empty()) return sharded::pattern_lh_cat(e, len, out);
     if (!e->theta_valid) return fail(IQHIP_ERR_INVALID, "iqhip_pattern_lh_cat needs iqhip_compute_theta first");
     if (!(len >= 0.0)) return fail(IQHIP_ERR_INVALID, "negative or NaN branch length");
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     const size_t count = (size_t)e->nptn * e->ncat;
     double *d_out = nullptr;
     HIPCHK(hipMalloc((void **)&d_out, sizeof(double) * count));
@@ -1985,7 +2117,7 @@ extern "C" int iqhip_set_boot_samples(iqhip_engine *e, const float *samples, int
     if (!e || (nsamples > 0 && !samples) || nsamples < 0) return fail(IQHIP_ERR_INVALID, "bad bootstrap samples");
     if (nsamples > 16384) return fail(IQHIP_ERR_INVALID, "at most 16384 bootstrap samples");
     if (!e->shards.empty()) return sharded::set_boot_samples(e, samples, nsamples);
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     HIPCHK(hipStreamSynchronize(e->stream));
     if (e->d_boot) HIPCHK(hipFree(e->d_boot));
     e->d_boot = nullptr;
@@ -2006,7 +2138,7 @@ extern "C" int iqhip_rell_async(iqhip_engine *e, iqhip_branch_end a, iqhip_branc
         return fail(IQHIP_ERR_UNSUPPORTED, "a sharded engine reduces its results itself: use the synchronous calls");
     if (e->nboot == 0) return fail(IQHIP_ERR_INVALID, "no bootstrap samples (iqhip_set_boot_samples)");
     if (e->nboot > e->result_cap) return fail(IQHIP_ERR_INVALID, "result buffer too small for the sample count");
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     int rc = scaled_pattern_lh(e, a, b);
     if (rc) return rc;
     HIPCHK(launch_rell(e, e->d_result));
@@ -2030,7 +2162,7 @@ extern "C" int iqhip_upload_partial(iqhip_engine *e, uint64_t key, const double 
                                     const int16_t *scale_num) {
     if (!e || !partial_lh || !scale_num) return fail(IQHIP_ERR_INVALID, "null argument");
     if (!e->shards.empty()) return sharded::upload_partial(e, key, partial_lh, scale_num);
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     int idx;
     int rc = slab_for_key(e, key, true, &idx);
     if (rc) return rc;
@@ -2081,7 +2213,7 @@ extern "C" int iqhip_timing_read(iqhip_engine *e, double *avg_ms, int64_t *launc
         if (launches) *launches = n0;
         return IQHIP_OK;
     }
-    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(use_device(e));
     HIPCHK(hipStreamSynchronize(e->stream));
     double total = 0.0;
     for (size_t i = 0; i < e->tev_used; i++) {
@@ -2095,4 +2227,48 @@ extern "C" int iqhip_timing_read(iqhip_engine *e, double *avg_ms, int64_t *launc
     if (launches) *launches = e->tev_launches;
     if (reset) { e->tev_used = 0; e->tev_launches = 0; }
     return IQHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// planning-only engine (CPU tests of build_plan + check_plan; no HIP call)
+// ---------------------------------------------------------------------------------------
+extern "C" int iqhip_debug_create_planner(iqhip_engine **out, int nstates, int ncat, int64_t nptn, int ntaxa, int num_cus,
+                                          int state_unknown, int nclass) {
+    if (!out) return fail(IQHIP_ERR_INVALID, "iqhip_debug_create_planner: out == NULL");
+    *out = nullptr;
+    if (nptn <= 0 || ntaxa < 2 || ncat < 1 || num_cus < 1 || nclass < 1 || nclass > ncat)
+        return fail(IQHIP_ERR_INVALID, "iqhip_debug_create_planner: bad shape");
+    if (nstates != 4 && nstates != 20 && nstates != 64)
+        return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_debug_create_planner: nstates must be 4, 20 or 64");
+    if (state_unknown < nstates || state_unknown > 255) return fail(IQHIP_ERR_INVALID, "state_unknown out of range");
+    iqhip_engine *e = new iqhip_engine();
+    e->planner = true;
+    e->check_plans = true;
+    e->num_cus = num_cus;
+    configure_engine(e, -1, nstates, nstates, ncat, nptn, ntaxa);
+    const size_t P = (size_t)e->nptn_pad;
+    e->d_states = fake_alloc<uint8_t>(e, (size_t)ntaxa * P);
+    e->dummy.plh = fake_alloc<double>(e, P * e->block);
+    e->dummy.sc = fake_alloc<int16_t>(e, P);
+    e->result_cap = 8 + 16384;
+    e->state_unknown = state_unknown;
+    e->nclass = nclass;
+    if (nclass > 1 && nstates == 4) {   // as set_model_common: a 4-state mixture runs on the matrix-core kernels
+        e->mfma = true;
+        e->lane_split = 1;
+        e->tile = 16;
+        e->ntiles = e->nptn_pad / 16;
+    }
+    e->mfma_pipelined = e->mfma_pipelined_ok && nclass == 1;
+    e->model_set = e->aln_set = true;
+    *out = e;
+    return IQHIP_OK;
+}
+
+// build the descriptors of one submission exactly as iqhip_update_partials would and validate them (check_plan)
+extern "C" int iqhip_debug_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops) {
+    if (!e || !e->planner) return fail(IQHIP_ERR_INVALID, "iqhip_debug_plan needs a planning-only engine");
+    if (nops < 0 || (nops > 0 && !ops)) return fail(IQHIP_ERR_INVALID, "bad ops array");
+    int last_dst = -1;
+    return build_plan(e, ops, nops, &last_dst, nullptr);
 }

@@ -149,6 +149,12 @@ __host__ __device__ inline void newton_update(NewtonState &s, double pdf, double
 
 struct iqhip_engine {
     int device = 0;
+    // planning-only engine (iqhip_debug_create_planner): no HIP call is ever made for it; "device" allocations are
+    // distinct fake addresses that are never dereferenced.  It exists so that build_plan and the plan check below run
+    // in CPU tests (tests/test_plan_check.py): the descriptors a kernel would receive are validated without a GPU.
+    bool planner = false;
+    uint64_t fake_next = 0x100000000000ull;
+    bool check_plans = false;  // IQHIP_CHECK_PLAN=1 (always on for a planner): validate every DevOp before upload
     int n = 0, ncat = 0, ntaxa = 0;
     // Binary data (2 states; phylotreesse.cpp:262-276 binds <Vec2d, 2, 2>): embedded EXACTLY into the 4-state kernels --
     // the eigen-system is padded block-diagonally (U = diag(U2, I2), eigenvalues (l0, l1, 0, 0)), so components 2, 3 of

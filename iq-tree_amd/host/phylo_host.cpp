@@ -500,6 +500,7 @@ struct MirrorPolicy : iqhip_adapter::EngineCalls<MirrorPolicy, PhyloTree> {
     typedef PhyloNeighbor Neighbor;
     static Node *node(Neighbor *nb) { return nb->node; }
     static double length(Neighbor *nb) { return nb->length; }
+    static void setLength(Neighbor *nb, double len) { nb->length = len; }
     static bool isLeaf(Node *n) { return n->isLeaf(); }
     static int degree(Node *n) { return n->degree(); }
     static int leafId(Node *n) { return n->id; }
@@ -722,7 +723,7 @@ void PhyloTree::optimizeOneBranch(PhyloNode *node1, PhyloNode *node2, bool clear
         optx = minimizeNewton(min_branch_length, current_len, max_branch_length, min_branch_length, d2l, maxNRStep);
     }
     if (optx > max_branch_length * 0.95) {  // newton raphson diverged, reset (phylotree.cpp:2167-2176)
-        current_it->length = current_it_back->length = optx;
+        // (both solvers leave the branch at the last evaluated length, as the reference's computeFuncDerv does)
         double opt_lh = computeLikelihoodFromBuffer();
         current_it->length = current_it_back->length = current_len;
         double orig_lh = computeLikelihoodFromBuffer();

@@ -404,6 +404,63 @@ class OracleTree:
             plh[:o] -= lp
         return total, plh
 
+    def minimize_newton(self, a, b, x1, xguess, x2, xacc, max_steps, theta=None):
+        """Optimization::minimizeNewton (optimization.cpp:388-465) over computeFuncDerv (phylotree.cpp:2135-2146:
+        f = -df, df = -ddf of computeLikelihoodDerv, NaN -> 0 as phylokernel.h:647-651) on branch (a, b), theta built
+        once (theta_computed, phylokernel.h:535-536).  Returns (optx, d2l, evaluated points, status): the list holds
+        every branch length the derivative was evaluated at, in order; status 'ok' | 'nonfinite' | 'maxsteps' for
+        the reference's two nrerror() exits."""
+        if theta is None:
+            theta, _ = self.theta(a, b)
+        evaluated = []
+
+        def func_derv(x):
+            evaluated.append(x)
+            df, ddf = self.derv(a, b, length=x, theta=theta)
+            if not np.isfinite(df):
+                df, ddf = 0.0, 0.0
+            return -df, -ddf
+
+        rts = min(max(xguess, x1), x2)
+        f, df = func_derv(rts)
+        d2l = df
+        if not (np.isfinite(f) and np.isfinite(df)):
+            return rts, d2l, evaluated, "nonfinite"
+        if df >= 0.0 and abs(f) < xacc:
+            return rts, d2l, evaluated, "ok"
+        if f < 0.0:
+            xl, xh = rts, x2
+        else:
+            xh, xl = rts, x1
+        dx = abs(xh - xl)
+        for j in range(1, max_steps + 1):
+            rts_old = rts
+            if df <= 0.0 or ((rts - xh) * df - f) * ((rts - xl) * df - f) >= 0.0:
+                dx = 0.5 * (xh - xl)
+                rts = xl + dx
+                d2l = df
+                if xl == rts:
+                    return rts, d2l, evaluated, "ok"
+            else:
+                dx = f / df
+                temp = rts
+                rts -= dx
+                d2l = df
+                if temp == rts:
+                    return rts, d2l, evaluated, "ok"
+            if abs(dx) < xacc or j == max_steps:
+                return rts_old, d2l, evaluated, "ok"
+            f, df = func_derv(rts)
+            if not (np.isfinite(f) and np.isfinite(df)):
+                return rts_old, d2l, evaluated, "nonfinite"
+            if df > 0.0 and abs(f) < xacc:
+                return rts, df, evaluated, "ok"
+            if f < 0.0:
+                xl = rts
+            else:
+                xh = rts
+        return 0.0, 0.0, evaluated, "maxsteps"
+
     def time_traversals(self, budget_s=15.0, min_reps=1):
         """cpu_baseline: repeat {clear; full traversal; root lnL}; returns (M upd/s, reps, seconds)."""
         reps, t0 = 0, time.perf_counter()

@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+# every plan the suites submit is validated on the host before it is uploaded (engine.hip check_plan)
+os.environ.setdefault("IQHIP_CHECK_PLAN", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -67,3 +67,15 @@ def test_unsupported_shapes_are_rejected(pkg):
     assert lib.iqhip_create(C.byref(e), 0, 4, 4, (1 << 32) // (16 * 8), 5) == 3
     assert b"4 GiB" in lib.iqhip_last_error()
     assert lib.iqhip_create(C.byref(e), 0, 4, 4, 10, 1) == 2    # ntaxa 1: INVALID
+
+
+def test_integration_file_parses_against_the_reference_headers():
+    """integration/phylotree_hip.cpp -- the reference-side binding -- under g++ -std=gnu++98 -fsyntax-only against scratch
+    copies of the reference's headers with the INTEGRATION.md hunks applied (tools/check_integration.sh; container only:
+    /root/reference does not exist on the GPU box)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("/root/reference absent")
+    r = subprocess.run(["bash", os.path.join(root, "tools", "check_integration.sh")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of library builds on ONE GPU box: tools/ab.sh <workload> <dir> [<dir> ...]  (dirs under iq-tree_amd/, e.g. lib lib_alt_base)
+set -e -o pipefail   # stop at the first failing step: a faulting kernel must not be followed by more runs on the box
 w=$1; shift
 for rep in 1 2; do
 for d in "$@"; do

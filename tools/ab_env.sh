@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of an environment switch on ONE GPU box: tools/ab_env.sh <workload> VAR=a VAR=b ...
+set -e -o pipefail   # stop at the first failing step: a faulting kernel must not be followed by more runs on the box
 w=$1; shift
 for rep in 1 2; do
 for kv in "$@"; do

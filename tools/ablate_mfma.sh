@@ -1,6 +1,7 @@
 #!/bin/bash
 # timing-only ablations of the matrix-core traversal kernels (tools/build_alt.sh variants); results of the variants are wrong
 # usage: tools/ablate_mfma.sh protein|codon  -> kernel ms per traversal for the shipped library and each lib_alt_* present
+set -e -o pipefail   # stop at the first failing step: a faulting kernel must not be followed by more runs on the box
 w=${1:-protein}
 for d in lib lib_alt_nostore lib_alt_noload lib_alt_nomem lib_alt_nomfma; do
   [ -d iq-tree_amd/$d ] || continue

@@ -1,6 +1,7 @@
 #!/bin/bash
 # per-kernel register / scratch / occupancy summary of one .hip file (compiler view, gfx950)
 # usage: tools/kernel_resources.sh iq-tree_amd/csrc/kernels_mfma.hip [extra hipcc flags]
+set -e -o pipefail   # stop at the first failing step: a faulting kernel must not be followed by more runs on the box
 f=$1; shift
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$f" -o /dev/null -Rpass-analysis=kernel-resource-usage "$@" 2>&1 |
 python3 -c '

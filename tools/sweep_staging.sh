@@ -1,5 +1,7 @@
+#!/bin/bash
+set -e -o pipefail   # stop at the first failing step: a faulting kernel must not be followed by more runs on the box
 mkdir -p gpurun_out/r2f
-(timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r2f/gpu_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r2f/gpu_tests.log); tail -5 gpurun_out/r2f/gpu_tests.log
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r2f/gpu_tests.log 2>&1   # (a failing suite ends the sweep)
 run() { # name env...
   n=$1; shift
   env "$@" python bench.py --workload $W --steps 40 --warmup 5 --no-cpu-baseline --sustain-seconds 0 > gpurun_out/r2f/${W}_$n.json 2> gpurun_out/r2f/${W}_$n.err
