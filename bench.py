@@ -14,7 +14,7 @@ Workloads (iq-tree_amd/synth.py BASELINE_SHAPES):
   codon    configs[4]: 64-state 50 x 20k, 20k/N per GPU (strong scaling)
 One RCCL all-reduce (SUM, f64) of the device result vector {lnL, sum_scale per node} per step when N > 1
 (SURVEY.md 8e).  Inputs are resident in HBM before the timed region.  One JSON line on rank 0; with the default
-workload the line also carries the configs[3] / configs[4] results of the same N under "also" (--no-also skips), so
+workload the line also carries the configs[2] / configs[3] / configs[4] results of the same N under "also" (--no-also skips), so
 that the driver's N = 1, 2, 4, 8 runs of the default command give the strong-scaling curves north_star names too.
 
 `python bench.py --gpus N` without WORLD_SIZE in the environment starts its N ranks itself (fresh child
@@ -231,47 +231,71 @@ def run_workload(args, D, pkg, synth, workload, steps, warmup, with_cpu_baseline
         step()
     avg_ms, launches = C.c_double(), C.c_int64()
     lib.iqhip_timing_read(eng, C.byref(avg_ms), C.byref(launches), 1)
+    coll_us, coll_n = C.c_double(), C.c_int64()
+    lib.iqhip_timing_collective_read(eng, C.byref(coll_us), C.byref(coll_n), 1)
     lib.iqhip_timing_enable(eng, 0)
 
     updates = steps * (T - 2) * P * D.world
     value = updates / dt / 1e6
     block = nst * model.ncat
-    # one traversal = one launch of the traversal kernel, or two for a staged plan (independent subtrees,
-    # then the ops above them): algorithmic work per launch = work per traversal / launches per traversal
+    # one traversal = one launch of the traversal kernel, or several for a staged plan (independent subtrees, then the
+    # ops above them).  Everything below is PER TRAVERSAL (= all its launches together): bytes / flops of the
+    # traversal over the sum of its launches' durations; kernel_avg_ms stays the per-launch average a profiler reports.
     lpt = max(1.0, launches.value / float(ntimed))
-    algo_bytes = algorithmic_bytes_per_traversal(T, P, block) / lpt
-    kern_s = avg_ms.value * 1e-3
-    achieved = algo_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
-    algo_flops = algorithmic_flops_per_traversal(T, P, nst, model.ncat) / lpt
-    if nst == 64:
-        tf = algo_flops / kern_s / 1e12 if kern_s > 0 else 0.0
-        roof = {"bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tf / MFMA_F64_PEAK_TFLOPS, "traffic": None,
-                "algorithmic_flops_per_launch": algo_flops, "algorithmic_GBps": achieved}
-    else:
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "algorithmic_TFLOPs": algo_flops / kern_s / 1e12 if kern_s > 0 else 0.0}
-    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    # (tools/profile_round.sh -> profiles/traffic.json); null when the shape was not profiled
+    kern_s = avg_ms.value * lpt * 1e-3
+    algo_bytes = algorithmic_bytes_per_traversal(T, P, block)
+    algo_flops = algorithmic_flops_per_traversal(T, P, nst, model.ncat)
+    floor_bytes = design_min_bytes_per_traversal(T, P, block)
+    st_b, ld_b = C.c_double(), C.c_double()
+    lib.iqhip_timing_plan_bytes(eng, C.byref(st_b), C.byref(ld_b))
+    plan_bytes = st_b.value + ld_b.value
+    # HBM bytes per traversal from the committed rocprofv3 PMC passes (tools/profile_round.sh -> profiles/traffic.json:
+    # FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, separate passes) when this exact shape was profiled; they are
+    # measurements of the same binary on another box, not of this run -- said so in traffic_source
+    pmc = None
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(workload)
         if tr and tr["ntaxa"] == T and tr["patterns_per_gpu"] == P and tr["ncat"] == model.ncat:
-            roof["traffic"] = tr["hbm_traffic_bytes_per_launch"]
-            roof["traffic_source"] = tr["source"]
-            # the counter-based figure beside the algorithmic one: bytes that really crossed the memory fabric
-            if kern_s > 0:
-                roof["frac_counter"] = tr["hbm_traffic_bytes_per_launch"] / kern_s / 1e9 / HBM_PEAK_GBS
+            pmc = tr
     except Exception:
         pass
-    floor_bytes = design_min_bytes_per_traversal(T, P, block)
-    roof.update({"kernel": kernel_name(pkg, nst, model.ncat, int(getattr(model, "nclass", 1))),
-                 "kernel_avg_ms": avg_ms.value, "launches": launches.value, "launches_per_traversal": lpt,
-                 "kernel_ms_per_traversal": avg_ms.value * lpt,
-                 # the design's own HBM floor: bytes it cannot avoid / the measured-achievable 6.3 TB/s
-                 "floor_ms": floor_bytes / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3,
-                 "floor_bytes_per_traversal": floor_bytes})
+    if pmc:
+        traffic = pmc["hbm_traffic_bytes_per_launch"] * pmc["launches_per_traversal"]
+        traffic_source = "PMC, NOT of this run: " + pmc["source"]
+    else:
+        traffic = None
+        traffic_source = "no PMC pass of this shape on file: priced with the launch's own descriptors (iqhip_timing_plan_bytes)"
+    phys_bytes = traffic if traffic is not None else plan_bytes
+    gbs = lambda nbytes: nbytes / kern_s / 1e9 if kern_s > 0 else 0.0   # noqa: E731
+    tfl = algo_flops / kern_s / 1e12 if kern_s > 0 else 0.0
+    hbm = {"achieved": gbs(phys_bytes), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs(phys_bytes) / HBM_PEAK_GBS}
+    mfma = {"achieved": tfl, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_F64_PEAK_TFLOPS,
+            "flops_per_traversal": algo_flops}
+    if nst == 64:
+        roof = dict(bound="mfma", **mfma)
+        roof["hbm"] = hbm
+    else:
+        roof = dict(bound="hbm", **hbm)
+        if nst == 20:
+            roof["mfma"] = mfma
+    assert roof["frac"] <= 1.0, "a roofline fraction above 1 means the byte / flop model is wrong, not that the chip is fast"
+    roof.update({
+        # bytes that crossed the memory fabric per traversal (PMC) or null; what `achieved` divides by the kernel time
+        "traffic": traffic, "traffic_source": traffic_source,
+        "bytes_priced": phys_bytes,
+        # the launch's own requests, live from this run's descriptors: stores exact, loads an upper bound of the fabric reads
+        "plan_bytes": {"stored": st_b.value, "loaded_upper_bound": ld_b.value},
+        # SURVEY 8(d) algorithmic bytes (every child vector read, every result written) / kernel time / HBM peak: a MODEL
+        # rate, not a roofline fraction -- the fused launch keeps most children in registers, so it can exceed 1
+        "algorithmic_bytes_per_traversal": algo_bytes, "frac_algorithmic": gbs(algo_bytes) / HBM_PEAK_GBS,
+        # the design's own floor: bytes it cannot avoid (results + counters written once, leaf states, root pass) at the
+        # measured-achievable 6.3 TB/s, against the kernel time
+        "floor_bytes_per_traversal": floor_bytes, "floor_ms": floor_bytes / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3,
+        "frac_of_floor": (floor_bytes / (HBM_ACHIEVABLE_GBS * 1e9)) / kern_s if kern_s > 0 else 0.0,
+        "kernel": (pmc or {}).get("kernel") or kernel_name(pkg, nst, model.ncat, int(getattr(model, "nclass", 1))),
+        "kernel_name_source": "rocprofv3 kernel trace (profiles/)" if pmc else "expected instantiation (not observed)",
+        "kernel_avg_ms": avg_ms.value, "launches": launches.value, "launches_per_traversal": lpt,
+        "kernel_ms_per_traversal": avg_ms.value * lpt})
     out = {
         "metric": "million pattern-node partial-likelihood updates/sec",
         "value": value,
@@ -293,6 +317,8 @@ def run_workload(args, D, pkg, synth, workload, steps, warmup, with_cpu_baseline
                    "collective": collective},
         "lnL": lnl,
         "host_overhead_ms_per_step": dt / steps * 1e3 - avg_ms.value * lpt,
+        # N > 1 (or --force-collective): the engine's own all-reduce, HIP events around it (incl. waiting for slower ranks)
+        "collective_us_per_step": coll_us.value * coll_n.value / float(ntimed) if coll_n.value else None,
         "roofline": roof,
     }
     if sustained:
@@ -340,7 +366,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=14.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true",
-                    help="default workload only: skip the configs[3] (dna4) and configs[4] (codon) results under 'also'")
+                    help="default workload only: skip the configs[2..4] (protein, dna4, codon) results under 'also'")
     ap.add_argument("--also", action="store_true", help="add the 'also' results to a non-default workload")
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="after the timed K steps, repeat the step for this long (activity evidence; 0 = off)")
@@ -372,11 +398,11 @@ def main():
     plain = not (args.ntaxa or args.patterns or args.ncat)
     if plain and ((default_command and not args.no_also) or args.also):
         also = []
-        for w in ("dna4", "codon"):
+        for w in ("protein", "dna4", "codon"):
             if w == args.workload:
                 continue
-            # (dna4 steps are 6 ms each; codon steps are 0.36 ms and need the clocks ramped: a handful of warm-up steps
-            # under-reports it by 10 %)
+            # (dna4 steps are 6 ms each; protein / codon steps are 1 / 0.36 ms and need the clocks ramped: a handful of
+            # warm-up steps under-reports them by 10 %)
             ks, kw = (max(20, args.steps // 4), max(5, args.warmup // 4)) if w == "dna4" else (max(200, args.steps), max(60, args.warmup))
             r = run_workload(args, D, pkg, synth, w, ks, kw, False)
             r.pop("sustained", None)

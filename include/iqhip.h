@@ -298,6 +298,15 @@ int iqhip_upload_partial(iqhip_engine *e, uint64_t key, const double *partial_lh
  * events on the engine's stream. */
 int iqhip_timing_enable(iqhip_engine *e, int on);
 int iqhip_timing_read(iqhip_engine *e, double *avg_ms, int64_t *launches, int reset);
+/* Bytes the traversal launches of the LAST submission store to / load from global memory, derived from its device
+ * descriptors (result vectors + counters; children that are neither register-resident nor parked; leaf state rows; the
+ * root-branch pass).  `stored` is exact; `loaded` is an upper bound of the fabric reads (same-launch re-reads may hit
+ * the L2 / Infinity Cache).  bench.py prices a launch with it when no PMC pass of the shape is on file. */
+int iqhip_timing_plan_bytes(iqhip_engine *e, double *stored, double *loaded);
+/* Engines with a communicator (iqhip_comm_init_rank): average duration in microseconds of the engine's own all-reduces
+ * since the last reset, HIP events on its stream around each ncclAllReduce while timing is enabled -- from the moment the
+ * stream reaches the collective to its completion, i.e. including the wait for slower ranks. */
+int iqhip_timing_collective_read(iqhip_engine *e, double *avg_us, int64_t *count, int reset);
 
 /* Debugging aid, no reference counterpart: a PLANNING-ONLY engine makes no HIP call and owns no device memory (its
  * vectors are distinct fake addresses).  iqhip_debug_plan turns an op list into the device descriptors exactly as

@@ -99,7 +99,23 @@ int comm_allreduce(iqhip_engine *e, int n) {
     Rccl *R;
     int rc = need_rccl(&R);
     if (rc) return rc;
+    // measurement hook (iqhip_timing_enable): HIP events on the engine's stream around the collective -- from the moment
+    // the stream reaches it (the kernels before it have finished) to its completion, i.e. incl. the wait for slower ranks
+    const bool timed = e->timing;
+    if (timed) {
+        if (e->cev_used == e->cev.size()) {
+            hipEvent_t a, b;
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            e->cev.emplace_back(a, b);
+        }
+        hipEventRecord(e->cev[e->cev_used].first, e->stream);
+    }
     ncclResult_t s = R->AllReduce(e->d_result, e->d_result, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)e->comm, e->stream);
+    if (timed) {
+        hipEventRecord(e->cev[e->cev_used].second, e->stream);
+        e->cev_used++;
+    }
     if (s != ncclSuccess) return nccl_fail(*R, "ncclAllReduce", s);
     return IQHIP_OK;
 }

@@ -247,6 +247,10 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
         hipEventDestroy(p.first);
         hipEventDestroy(p.second);
     }
+    for (auto &p : e->cev) {
+        hipEventDestroy(p.first);
+        hipEventDestroy(p.second);
+    }
     if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1149,11 +1153,15 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         } else {
             budget = (e->lds_budget_bytes / 8) - 128 - B;
         }
+        const bool tables_in_lds = e->mfma && e->mfma_pipelined && e->n == 20 && e->plan_nleaf_tabs > 0;
         int chunk_start = 0, used = e->mfma ? 0 : e->wg_size / 8, regs = 0, max_used = 0, slots = 1, max_slots = 1;
         for (int k = 0; k < nops; k++) {
             DevOp &d = e->h_ops[k];
-            const int szl = (!e->mfma && d.left_kind == CHILD_LEAF) ? 6 * B : B;
-            const int szr = (!e->mfma && d.right_kind == CHILD_LEAF) ? 6 * B : B;
+            // a LEAF child's region: 4 states -- exponentials + the 5-row K2 table; 20 states with leaf tables -- the
+            // child's whole K2 table [ncat][STATE_UNKNOWN][n], copied from the table buffer when the chunk is filled
+            const int leaf_sz = !e->mfma ? 6 * B : (tables_in_lds ? (int)leaf_table_doubles(e) : B);
+            const int szl = d.left_kind == CHILD_LEAF ? leaf_sz : B;
+            const int szr = d.right_kind == CHILD_LEAF ? leaf_sz : B;
             // 4-state path: each leaf child also stages one state byte per thread in LDS
             const int nleaf = (d.left_kind == CHILD_LEAF) + (d.right_kind == CHILD_LEAF);
             const int need = szl + szr + (e->mfma ? 0 : nleaf * e->wg_size / 8);
@@ -1324,6 +1332,8 @@ static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, 
     } else if (has_root) HIPCHK(launch_reduce(e, 0, 2 + nops, nwaves));
     else if (!skip_reduce) HIPCHK(launch_reduce(e, 2, nops, nwaves));
     e->last_nops = nops;
+    e->last_has_root = has_root;
+    e->last_root_loads_b = has_root && br.b_kind != CHILD_PREV;
     return IQHIP_OK;
 }
 
@@ -2193,6 +2203,57 @@ extern "C" int iqhip_timing_enable(iqhip_engine *e, int on) {
         return IQHIP_OK;
     }
     e->timing = on != 0;
+    return IQHIP_OK;
+}
+
+// average duration (us) of the engine's own all-reduces since the last reset, HIP events on its stream (comm.hip)
+extern "C" int iqhip_timing_collective_read(iqhip_engine *e, double *avg_us, int64_t *count, int reset) {
+    if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    if (!e->shards.empty()) e = e->shards[0];   // (grouped all-reduce of a single-process front: not bracketed; reads 0)
+    HIPCHK(use_device(e));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    double total = 0.0;
+    for (size_t i = 0; i < e->cev_used; i++) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e->cev[i].first, e->cev[i].second));
+        total += ms;
+    }
+    if (avg_us) *avg_us = e->cev_used ? total * 1e3 / (double)e->cev_used : 0.0;
+    if (count) *count = (int64_t)e->cev_used;
+    if (reset) e->cev_used = 0;
+    return IQHIP_OK;
+}
+
+// bytes the last submission's traversal launches ask the memory system for, from its descriptors: every result vector
+// and its counters stored once; the children that are neither the previous result nor parked (streamed / second memory
+// child) loaded once each; leaf state rows; the root-branch pass (its vector unless it is the previous result, ptn_freq,
+// ptn_invar, _pattern_lh).  Loads of vectors written earlier in the same launch may be served by the L2 / Infinity Cache,
+// so `loaded` bounds the fabric reads from above; `stored` is exact.
+extern "C" int iqhip_timing_plan_bytes(iqhip_engine *e, double *stored, double *loaded) {
+    if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    double st = 0.0, ld = 0.0;
+    if (!e->shards.empty()) {
+        for (iqhip_engine *c : e->shards) {
+            double a = 0.0, b = 0.0;
+            int rc = iqhip_timing_plan_bytes(c, &a, &b);
+            if (rc) return rc;
+            st += a; ld += b;
+        }
+    } else {
+        const double P = (double)e->nptn_pad, V = (double)e->block * 8.0;
+        for (int k = 0; k < e->last_nops && e->h_ops; k++) {
+            const DevOp &d = e->h_ops[k];
+            st += P * (V + 2.0);
+            if (d.left_kind == CHILD_LEAF) ld += P; else if (d.left_kind == CHILD_PF || d.left_kind == CHILD_LOAD) ld += P * (V + 2.0);
+            if (d.right_kind == CHILD_LEAF) ld += P; else if (d.right_kind == CHILD_LOAD) ld += P * (V + 2.0);
+        }
+        if (e->last_has_root) {
+            st += P * 8.0;
+            ld += P * 16.0 + (e->last_root_loads_b ? P * V : 0.0) + P;
+        }
+    }
+    if (stored) *stored = st;
+    if (loaded) *loaded = ld;
     return IQHIP_OK;
 }
 

@@ -335,8 +335,11 @@ struct iqhip_engine {
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;
     size_t tev_used = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> cev;  // ... around the engine's own all-reduces (comm.hip)
+    size_t cev_used = 0;
     int64_t tev_launches = 0;  // traversal-kernel launches inside the recorded brackets
     int last_nops = 0;
+    bool last_has_root = false, last_root_loads_b = false;  // ... of the last submission (iqhip_timing_plan_bytes)
     // the last submission's reduction was folded into its kernel and the host polls: the kernel wrote only the rows it
     // summed plus, behind them, the number of flagged sum_scale rows; read_result zero-fills the rest when that is 0
     int folded_rows = -1;

@@ -439,10 +439,11 @@ hipError_t launch_leaf_tables(iqhip_engine *e, const TabJob *d_jobs, int njobs) 
 // TAB: LEAF children are table look-ups (k_leaf_tables) instead of U * (ex .* tip) products on the matrix pipe.
 template <int N, int C, int WG, int CS, bool TAB>
 __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vblock) {
-    // TABPF: the table rows of a step are requested one (op, category) step ahead (20 states: a category step is
-    // only 15 MFMAs long, too short to cover an L2 round trip; 64 states: the step is the whole op and the 2 x 16
-    // extra registers would spill, so the rows are requested at the start of the step itself)
-    constexpr bool TABPF = TAB && (N < 64);
+    // TABL (20 states): the K2 tables of the chunk's LEAF children are copied into LDS when the chunk is filled (the four
+    // waves of a workgroup walk the same ops) and a lane reads its pattern's row with ds_read_b128: gathered from global
+    // memory the rows cost more than the matrix products they replace once result stores are in flight (r02: 1.07 vs
+    // 1.03 ms; even without any other traffic 0.78 vs 0.89 ms where the products removed are 34 % of the matrix work)
+    constexpr bool TABL = TAB && (N < 64);
     // rows of U / U^-1: MTF full 16-row tiles on v_mfma_f64_16x16x4_f64 plus, for N = 20, the four
     // left-over rows on v_mfma_f64_4x4x4_4b_f64 (4 blocks = the tile's 4 groups of 4 patterns).
     // Lane layouts of the 4x4x4 form (measured, tools/mfma444_probe.hip): A[i][k] at lane
@@ -457,14 +458,16 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
     constexpr int CT = C * CS;   // categories of the block
     constexpr int B = CT * N;
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    // (20 states keep the fragments of U / U^-1 in registers, AREG below: no LDS image)
+    constexpr int IMG1 = (N < 64) ? 0 : MTF * KS * 64, IMG4 = (N < 64) ? 0 : (TAIL4 ? KS * 64 : 0);
     double *sU = smem;                           // [MTF][KS][64]
-    double *sUi = sU + MTF * KS * 64;            // [MTF][KS][64]
-    double *sU4 = sUi + MTF * KS * 64;           // [KS][64] tail rows (TAIL4)
-    double *sUi4 = sU4 + (TAIL4 ? KS * 64 : 0);
+    double *sUi = sU + IMG1;                     // [MTF][KS][64]
+    double *sU4 = sUi + IMG1;                    // [KS][64] tail rows (TAIL4)
+    double *sUi4 = sU4 + IMG4;
     // tip_partial_lh rows of states < N (= columns of U^-1): a plain [N][N] copy when it is small,
     // otherwise read out of the U^-1 fragment image
     constexpr bool TIP_COPY = (N * N * 8 <= 4096);
-    double *sUiT = sUi4 + (TAIL4 ? KS * 64 : 0);
+    double *sUiT = sUi4 + IMG4;
     double *sTipx = sUiT + (TIP_COPY ? N * N : 0);
     const int nx = A.state_unknown + 1 - N;
     double *sReg = sTipx + nx * N;
@@ -547,19 +550,6 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
     constexpr bool HOLDS = (N < 64) && (CS == 1);
     LDS_AS double *const hold = HOLDS && A.hold_off >= 0 ? (LDS_AS double *)(smem + A.hold_off) + (size_t)wave * 16 * B + lane : nullptr;
     int hold_sc = 0;
-    v4f64 nL[MTF], nR[MTF];   // TABPF: table rows of the coming step
-    double nL4 = 0.0, nR4 = 0.0;
-#pragma unroll
-    for (int m = 0; m < MTF; m++) { nL[m] = (v4f64){0, 0, 0, 0}; nR[m] = (v4f64){0, 0, 0, 0}; }
-    if (TABPF) {
-        const CONST_AS DevOp &f = ops[k_begin];
-        const double *rl = f.tabL + ((size_t)coff * S + (sLn < S ? sLn : 0)) * N + 4 * g;
-        const double *rr = f.tabR + ((size_t)coff * S + (sRn < S ? sRn : 0)) * N + 4 * g;
-#pragma unroll
-        for (int m = 0; m < MTF; m++) { nL[m] = *reinterpret_cast<const v4f64 *>(rl + 16 * m); nR[m] = *reinterpret_cast<const v4f64 *>(rr + 16 * m); }
-        if (TAIL4) { nL4 = rl[16 * MTF - 3 * g]; nR4 = rr[16 * MTF - 3 * g]; }
-    }
-
     int k = k_begin;
     while (k < k_end) {
         const int kn = ops[k].chunk_nops;
@@ -570,6 +560,20 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
             if (TAB && (child ? d.right_kind : d.left_kind) == CHILD_LEAF) continue;  // a table child needs no exponentials
             const double len = child ? d.right_len : d.left_len;
             sReg[(child ? d.lds_right : d.lds_left) + e] = exp(A.eval[e % N] * (A.rates[e / N] * len));
+        }
+        if constexpr (TABL) {
+            // the leaf children's tables [CT][S][N] (k_leaf_tables, L2-resident): straight 16-byte copies into their regions
+            const int tab2 = CT * S * N / 2;   // double2 per table (N is even)
+            for (int o = 0; o < kn; o++) {
+                const CONST_AS DevOp &d = ops[k + o];
+#pragma unroll
+                for (int child = 0; child < 2; child++) {
+                    if ((child ? d.right_kind : d.left_kind) != CHILD_LEAF) continue;
+                    const double2 *src = reinterpret_cast<const double2 *>(child ? d.tabR : d.tabL);
+                    double2 *dst2 = reinterpret_cast<double2 *>(sReg + (child ? d.lds_right : d.lds_left));
+                    for (int t = threadIdx.x; t < tab2; t += WG) dst2[t] = src[t];
+                }
+            }
         }
         __syncthreads();
         if (!active) { k += kn; continue; }
@@ -615,8 +619,8 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
                 return as_lds(sUi)[aidx<KS>(i >> 4, st >> 2, (st & 3) * 16 + (i & 15))];  // U^-1[i][st] in the A image
             };
             // TAB: this lane's slice of the leaf children's table rows (4 contiguous doubles per M-tile)
-            const double *rowL = op.tabL + (size_t)(sL < S ? sL : 0) * N + 4 * g;
-            const double *rowR = op.tabR + (size_t)(sR < S ? sR : 0) * N + 4 * g;
+            const double *rowL = (TABL ? sReg + op.lds_left : op.tabL) + (size_t)(sL < S ? sL : 0) * N + 4 * g;
+            const double *rowR = (TABL ? sReg + op.lds_right : op.tabR) + (size_t)(sR < S ? sR : 0) * N + 4 * g;
             double *dst = op.dst + tbase;
             unsigned lmax = 0;
 #pragma unroll
@@ -741,27 +745,12 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
                 };
                 // TAB: a leaf child's product is its pattern's row of the (L2-resident) table: requested before the
                 // other child's MFMA chain, multiplied in after it
-                v4f64 cL[MTF], cR[MTF];   // TABPF: this step's rows (requested one step ago)
-                double cL4 = 0.0, cR4 = 0.0;
-                if constexpr (TABPF) {
-#pragma unroll
-                    for (int m = 0; m < MTF; m++) { cL[m] = nL[m]; cR[m] = nR[m]; }
-                    cL4 = nL4; cR4 = nR4;
-                    // request the next step's rows: (k, c+1) or (k+1, 0); non-leaf children point at a valid dummy
-                    const CONST_AS DevOp &nq = (c + 1 < C) ? op : nxop;
-                    const int nsL = (c + 1 < C) ? sL : sLn, nsR = (c + 1 < C) ? sR : sRn;
-                    const int cn = (c + 1 < C) ? c + 1 : 0;
-                    const double *rl = nq.tabL + ((size_t)(coff + cn) * S + (nsL < S ? nsL : 0)) * N + 4 * g;
-                    const double *rr = nq.tabR + ((size_t)(coff + cn) * S + (nsR < S ? nsR : 0)) * N + 4 * g;
-#pragma unroll
-                    for (int m = 0; m < MTF; m++) { nL[m] = *reinterpret_cast<const v4f64 *>(rl + 16 * m); nR[m] = *reinterpret_cast<const v4f64 *>(rr + 16 * m); }
-                    if (TAIL4) { nL4 = rl[16 * MTF - 3 * g]; nR4 = rr[16 * MTF - 3 * g]; }
-                }
                 auto table_row = [&](bool right, v4f64 (&Y)[MTF], double &y4) {
-                    if constexpr (TABPF) {
+                    if constexpr (TABL) {
+                        const LDS_AS double *r = as_lds((right ? rowR : rowL) + (size_t)(coff + c) * S * N);
 #pragma unroll
-                        for (int m = 0; m < MTF; m++) Y[m] = right ? cR[m] : cL[m];
-                        y4 = right ? cR4 : cL4;
+                        for (int m = 0; m < MTF; m++) Y[m] = *reinterpret_cast<const LDS_AS v4f64 *>(r + 16 * m);
+                        if (TAIL4) y4 = r[16 * MTF - 3 * g];   // (row carries +4g: tail row 16*MTF + g)
                     } else {
                         const double *r = (right ? rowR : rowL) + (size_t)(coff + c) * S * N;
 #pragma unroll
@@ -1297,7 +1286,8 @@ static hipError_t launch_trav_rows64(iqhip_engine *e, TravMArgs &A) {
 // LDS doubles of k_traverse_mfma2 that do not depend on the plan (A images, tail images, U^-1 transposed)
 int mfma2_fixed_lds_doubles(int n) {
     const int mtf = n / 16, ks = n / 4;
-    return 2 * mtf * ks * 64 + ((n % 16) == 4 ? 2 * ks * 64 : 0) + (n * n * 8 <= 4096 ? n * n : 0);
+    const int images = n < 64 ? 0 : 2 * mtf * ks * 64 + ((n % 16) == 4 ? 2 * ks * 64 : 0);   // (20 states: fragments in registers)
+    return images + (n * n * 8 <= 4096 ? n * n : 0);
 }
 
 template <int N, int C, int CS = 1, bool TAB = false>

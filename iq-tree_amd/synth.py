@@ -95,6 +95,54 @@ def random_reversible_model(n, seed, alpha=0.9, ncat=4, pinvar=0.0, min_freq=Non
     return reversible_model(R, freqs, alpha, ncat, pinvar, name="GTR%d+G%d" % (n, ncat))
 
 
+# standard genetic code (NCBI table 1) in T,C,A,G order; codon states are numbered 16a+4b+c with A,C,G,T = 0..3
+# (alignment.cpp:470-472), stop codons included: 64 states
+_CODE_TCAG = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"
+
+
+def standard_genetic_code():
+    """amino acid (or '*') per codon state 16a+4b+c, A,C,G,T = 0..3"""
+    tcag = {0: 2, 1: 1, 2: 3, 3: 0}  # A,C,G,T -> position in T,C,A,G
+    return "".join(_CODE_TCAG[16 * tcag[i // 16] + 4 * tcag[(i % 16) // 4] + tcag[i % 4]] for i in range(64))
+
+
+def gy94_sense_model(kappa=2.0, omega=0.5, nt_freqs=(0.25, 0.26, 0.25, 0.24)):
+    """GY94 (Goldman & Yang 1994; the reference's ModelCodon "GY", model/modelcodon.cpp:454-560) on the 61 sense
+    codons with F1X4 frequencies: rate 0 between codons that differ at more than one position, x kappa for a
+    transition, x omega for a non-synonymous change.  For SIMULATING codon data only (the evaluated model comes
+    from the C++ producer, iq-tree_amd/host/model_host.cpp).  -> (61-state Model, codon state of each of the 61)."""
+    code = standard_genetic_code()
+    sense = [i for i in range(64) if code[i] != "*"]
+    nt = np.asarray(nt_freqs, dtype=np.float64)
+    n = len(sense)
+    R = np.zeros((n, n))
+    for x, i in enumerate(sense):
+        a = (i // 16, (i % 16) // 4, i % 4)
+        for y, j in enumerate(sense):
+            if i == j:
+                continue
+            b = (j // 16, (j % 16) // 4, j % 4)
+            diff = [(p, q) for p, q in zip(a, b) if p != q]
+            if len(diff) != 1:
+                continue
+            r = kappa if abs(diff[0][0] - diff[0][1]) == 2 else 1.0   # A<->G, C<->T
+            if code[i] != code[j]:
+                r *= omega
+            R[x, y] = r
+    f = np.array([nt[i // 16] * nt[(i % 16) // 4] * nt[i % 4] for i in sense])
+    return reversible_model(R, f, None, 1, 0.0, name="GY94sim"), np.array(sense, dtype=np.uint8)
+
+
+def codon_phylip(states):
+    """states[ntaxa, nsites] of codon codes (16a+4b+c) -> PHYLIP text of 3*nsites nucleotide columns"""
+    lut = np.array([[ord("ACGT"[i // 16]), ord("ACGT"[(i % 16) // 4]), ord("ACGT"[i % 4])] for i in range(64)], dtype=np.uint8)
+    ntaxa, nsites = states.shape
+    rows = ["%d %d" % (ntaxa, 3 * nsites)]
+    for t in range(ntaxa):
+        rows.append("%d %s" % (t, lut[states[t]].reshape(-1).tobytes().decode()))
+    return "\n".join(rows) + "\n"
+
+
 # -------------------------------------------------------------------------------------------
 # trees
 # -------------------------------------------------------------------------------------------
@@ -288,7 +336,44 @@ def baseline_model(workload, ncat=0):
         return gtr_model(rates6=(1.5, 2.4, 1.8, 1.9, 2.8, 1.0), freqs=(0.25, 0.26, 0.25, 0.24), alpha=0.9, ncat=ncat), None
     # random reversible 20-/64-state model of the LG+G4 / GY shape (the reference's empirical matrices are
     # constants of its source and are not copied); codon: ncat = 1 as GY+F1X4, stop-codon-like rare states
-    return random_reversible_model(nst, 7, alpha=0.9 if ncat > 1 else None, ncat=ncat, min_freq=1e-4), None
+    m = random_reversible_model(nst, 7, alpha=0.9 if ncat > 1 else None, ncat=ncat, min_freq=1e-4)
+    if workload == "protein":
+        m.name = "LG-shaped random reversible 20-state matrix +G%d{0.9}" % ncat
+    return m, None
+
+
+class ProducedModel:
+    """model arrays as the C++ producers return them (iqtree_amd.Alignment.build_model)"""
+
+    def __init__(self, m, name):
+        self.eval, self.evec, self.inv_evec = m.eval, m.evec.reshape(-1), m.inv_evec.reshape(-1)
+        self.rates, self.props, self.freqs = m.rates, m.props, m.state_freq
+        self.nstates, self.ncat, self.pinvar, self.name = m.nstates, m.ncat, m.p_invar, name
+        self.Q = None
+
+
+def codon_gy94_workload(T, P, shard):
+    """BASELINE configs[4] as the reference runs it (`-st CODON -m GY+F1X4`): codon sites simulated under
+    GY94 on the 61 sense codons, written as a nucleotide PHYLIP alignment, read back by the package's own reader
+    (codon translation, pattern compression: alignment_host.cpp) and given the model the C++ GY94 producer builds from
+    that alignment (F1X4 frequencies, rate matrix, eigen-system: model_host.cpp).  kappa 2, omega 0.5 fixed."""
+    import sys
+    pkg = sys.modules["iqtree_amd"]
+    sim, sense = gy94_sense_model(2.0, 0.5)
+    nwk = random_tree_newick(T, 1)
+    nsites = int(P * 1.02) + 64
+    while True:
+        st = simulate_alignment(nwk, sim, nsites, 1000 + shard)
+        pat, _ = compress_patterns(st)
+        if pat.shape[1] >= P:
+            break
+        nsites = int(nsites * 1.3)
+    aln = pkg.Alignment(content=codon_phylip(sense[pat[:, :P]]), seq_type="CODON")
+    states, freq, _, _ = aln.arrays()
+    if states.shape[1] != P:
+        raise RuntimeError("codon reader returned %d patterns, expected %d" % (states.shape[1], P))
+    model = ProducedModel(aln.build_model("GY{2.0,0.5}+F1X4"), "GY94{kappa=2,omega=0.5}+F1X4")
+    return nwk, np.ascontiguousarray(states), freq.copy(), model
 
 
 def baseline_workload(workload, ntaxa=0, patterns=0, shard=0, ncat=0):
@@ -296,6 +381,8 @@ def baseline_workload(workload, ntaxa=0, patterns=0, shard=0, ncat=0):
     (seed 1); shard r simulates its own sites (seed 1000 + r), as one rank of a pattern-sharded run does."""
     T0, P0, nst, C0, seq_type = BASELINE_SHAPES[workload]
     T, P = ntaxa or T0, patterns or P0
+    if workload == "codon":
+        return codon_gy94_workload(T, P, shard)
     model, sim_model = baseline_model(workload, ncat)
     nwk = random_tree_newick(T, 1)
     nsites = int(P * 1.02) + 64
