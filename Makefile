@@ -10,7 +10,7 @@ CSRC       := $(PKG)/csrc
 HOST       := $(PKG)/host
 LIBDIR     := $(PKG)/lib
 HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result
-HIP_SRCS   := $(CSRC)/engine.hip $(CSRC)/kernels_valu4.hip $(CSRC)/kernels_mfma.hip $(CSRC)/kernels_newton.hip $(CSRC)/kernels_rell.hip $(CSRC)/comm.hip $(CSRC)/sharded.hip
+HIP_SRCS   := $(CSRC)/engine.hip $(CSRC)/kernels_valu4.hip $(CSRC)/kernels_mfma.hip $(CSRC)/kernels_newton.hip $(CSRC)/kernels_sweep.hip $(CSRC)/kernels_rell.hip $(CSRC)/comm.hip $(CSRC)/sharded.hip
 HIP_OBJS   := $(patsubst $(CSRC)/%.hip,$(LIBDIR)/%.o,$(HIP_SRCS))
 
 all: $(LIBDIR)/libiqhip.so $(LIBDIR)/libiqhost.so $(LIBDIR)/iqhip_lnl oracle/liblh_oracle.so
@@ -25,7 +25,7 @@ $(LIBDIR)/libiqhip.so: $(HIP_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJS) -ldl
 
 HOST_SRCS  := $(HOST)/phylo_host.cpp $(HOST)/iqhost_c.cpp $(HOST)/model_host.cpp $(HOST)/alignment_host.cpp $(HOST)/iqmodel_c.cpp
-HOST_HDRS  := $(HOST)/phylo_host.h $(HOST)/model_host.h $(HOST)/alignment_host.h include/iqhip.h
+HOST_HDRS  := $(HOST)/phylo_host.h $(HOST)/model_host.h $(HOST)/alignment_host.h include/iqhip.h include/iqhip_adapter.h
 
 $(LIBDIR)/libiqhost.so: $(HOST_SRCS) $(HOST_HDRS) $(LIBDIR)/libiqhip.so
 	$(CXX) -O2 -std=c++17 -fPIC -shared -Wall -o $@ $(HOST_SRCS) -L$(LIBDIR) -liqhip -Wl,-rpath,'$$ORIGIN'

@@ -267,10 +267,35 @@ typedef struct iqhip_branch_task {
 typedef struct iqhip_branch_result {
     double optx, d2l, lnl;
     int32_t nsteps;
-    int32_t status; /* 0 ok, 2 non-finite derivative, 3 step limit reached (optx is still the last iterate) */
+    int32_t status; /* 0 ok, 2 non-finite derivative, 3 step limit reached (optx is still the last iterate), 5 (sweeps) diverged-solve rule applied */
 } iqhip_branch_result;
 int iqhip_optimize_branch_batch(iqhip_engine *e, const iqhip_branch_task *tasks, int ntasks,
                                 double *sum_scale /* sum of nops, may be NULL */, iqhip_branch_result *results);
+
+/* A whole branch-length sweep in one submission: PhyloTree::optimizeAllBranches' loop `for every branch in pre-order:
+ * optimizeOneBranch(node1, node2, clearLH = true, maxNRStep)` (phylotree.cpp:2252-2332, 2148-2192).  Step j runs the node
+ * updates that are pending at both ends of its branch, builds theta and solves for the branch length exactly as
+ * iqhip_optimize_branch does; the length of a child branch that an EARLIER step of the same sweep optimised is not known
+ * to the host when the sweep is submitted, so the op refers to it by step number: len_from[2k] / len_from[2k+1] >= 0
+ * replaces ops[k].left_len / right_len by the accepted length of that step (the engine reads it from device memory when
+ * the op runs); -1 keeps the value in the op.  The caller lists the steps as if every step changed its branch
+ * (optimizeOneBranch's clearReversePartialLh on both sides of the branch).
+ * diverge_frac > 0 applies optimizeOneBranch's "newton raphson diverged, reset" rule (phylotree.cpp:2167-2176, 0.95 there)
+ * inside the sweep: a result above diverge_frac * x2 is kept only if the branch lnL there is not below the lnL at
+ * xguess; results[j].status = 5 reports that the rule ran.  results[j].lnl is not filled.  sum_scale receives the per-op
+ * values of all steps, concatenated.  Two launches per step, one host round trip per sweep; on sharded engines (every
+ * Newton step contains an all-reduce) and with +ASC the steps run one after the other inside this call. */
+typedef struct iqhip_sweep_step {
+    const iqhip_node_op *ops;
+    const int32_t *len_from; /* NULL or 2 * nops entries */
+    int32_t nops;
+    int32_t _pad;
+    iqhip_branch_end a, b;
+    double xguess; /* the branch's current length */
+} iqhip_sweep_step;
+int iqhip_optimize_sweep(iqhip_engine *e, const iqhip_sweep_step *steps, int nsteps, double x1, double x2, double xacc,
+                         int max_steps, double diverge_frac, double *sum_scale /* sum of nops, may be NULL */,
+                         iqhip_branch_result *results);
 
 /* Consumers of the device-resident _pattern_lh (so -wsl / UFBoot need no full-vector round trip per tree).
  * iqhip_fetch_pattern_lh_scaled: PhyloTree::computePatternLikelihood (phylotree.cpp:1200-1230) for the

@@ -39,6 +39,11 @@
  *   double lnlFromTheta(Tree *, double len);
  *   double optimizeBranch(Tree *, Plan<X> &, iqhip_branch_end a, iqhip_branch_end b, double xguess, int max_steps,
  *                         double *sum_scale, int *nsteps);
+ *   // only for optimizeBranchSweep:
+ *   void clearReversePartialLh(Node *node, Node *dad);      // PhyloNode::clearReversePartialLh (phylonode.cpp:43-52)
+ *   void setCurrent(Tree *, Neighbor *it, Neighbor *back);  // current_it / current_it_back
+ *   void optimizeSweep(Tree *, const iqhip_sweep_step *, int nsteps, int max_steps, double diverge_frac, double *sum_scale,
+ *                      iqhip_branch_result *);
  */
 #ifndef IQHIP_ADAPTER_H_
 #define IQHIP_ADAPTER_H_
@@ -62,6 +67,10 @@ struct Plan {
      * 50-taxon traversal cost 250 heap calls, most of its 13 us */
     std::vector<typename X::Neighbor *> kid_flat;
     std::vector<uint32_t> kid_off; /* [size() + 1] */
+    /* per op: the child neighbours whose branch lengths are ops[k].left_len / right_len ([2k], [2k+1]; NULL for the
+     * zero-length hand-over of a multifurcating node's running product) -- what a sweep needs to refer to lengths that
+     * are not known yet (optimizeBranchSweep) */
+    std::vector<typename X::Neighbor *> len_nb;
     Plan() {
         ops.reserve(64);
         dst.reserve(64);
@@ -195,12 +204,15 @@ inline void collectPlan(typename X::Tree *tree, typename X::Neighbor *dad_branch
         memset(&op, 0, sizeof(op));
         if (i == 1) {
             setChild<X>(op, true, kids[0]);
+            plan.len_nb.push_back(kids[0]);
         } else { /* the running product of children 0..i-1 */
             op.left_leaf = -1;
             op.left_key = tempKey(dst, (int)i - 2);
             op.left_len = 0.0;
+            plan.len_nb.push_back((Neighbor *)0);
         }
         setChild<X>(op, false, kids[i]);
+        plan.len_nb.push_back(kids[i]);
         op.dst_key = last ? dst : tempKey(dst, (int)i - 1);
         op.flags = last ? 0u : (uint32_t)IQHIP_OP_NO_SCALE;
         plan.ops.push_back(op);
@@ -276,6 +288,12 @@ struct EngineCalls {
                                      max_steps, sum_scale, &optx, &d2l, nsteps),
             "iqhip_optimize_branch");
         return optx;
+    }
+    static void optimizeSweep(Tree *t, const iqhip_sweep_step *steps, int nsteps, int max_steps, double diverge_frac,
+                              double *sum_scale, iqhip_branch_result *results) {
+        chk(t, iqhip_optimize_sweep(X::engine(t), steps, nsteps, X::minBranchLength(t), X::maxBranchLength(t),
+                                    X::minBranchLength(t), max_steps, diverge_frac, sum_scale, results),
+            "iqhip_optimize_sweep");
     }
 };
 
@@ -376,6 +394,77 @@ inline double minimizeNewtonOnBranch(typename X::Tree *tree, double current_len,
     if (nsteps) *nsteps = steps;
     if (plan_out) *plan_out = plan;
     return optx;
+}
+
+/* PhyloTree::optimizeAllBranches' inner loop (phylotree.cpp:2285-2290)
+ *     for (j = 0; j < nodes1.size(); j++) optimizeOneBranch(nodes1[j], nodes2[j], true, maxNRStep);
+ * as ONE engine submission (iqhip_optimize_sweep).  The plans of all branches are collected up front with the reference's
+ * own flag logic, pretending that every optimizeOneBranch changes its branch -- which is what makes it call
+ * clearReversePartialLh on both sides (phylotree.cpp:2186-2189); a child branch optimised earlier in the sweep is
+ * referred to by its step number (its length only exists on the device until the sweep returns).  Afterwards the
+ * lengths, lh_scale_factors, current_it / current_it_back and theta_computed are what the loop would have left
+ * (theta_all is that of the last branch).  Needs two more policy functions: X::clearReversePartialLh(node, dad) and
+ * X::setCurrent(tree, it, back); X::optimizeSweep has a default in EngineCalls. */
+template <class X>
+inline void optimizeBranchSweep(typename X::Tree *tree, typename X::Node *const *nodes1, typename X::Node *const *nodes2,
+                                int nbranches, int max_steps, double diverge_frac, int *nevals = 0) {
+    typedef typename X::Neighbor Neighbor;
+    typedef typename X::Node Node;
+    if (nbranches <= 0) return;
+    X::ensureBuffers(tree);
+    X::sync(tree);
+    std::vector<Plan<X> > plans((size_t)nbranches);
+    std::vector<std::vector<int32_t> > len_from((size_t)nbranches);
+    std::vector<iqhip_sweep_step> steps((size_t)nbranches);
+    std::vector<Neighbor *> opt_nb; /* neighbours (both directions) of the branches optimised so far, with their step */
+    std::vector<int32_t> opt_step;
+    size_t total_ops = 0;
+    for (int j = 0; j < nbranches; j++) {
+        Neighbor *it = X::findNeighbor(nodes1[j], nodes2[j]), *back = X::findNeighbor(nodes2[j], nodes1[j]);
+        Neighbor *dad_branch = it, *node_branch; /* as optimizeOneBranch: current_it = node1's neighbour towards node2 */
+        Node *dad = nodes1[j], *node;
+        orientBranch<X>(dad_branch, dad, node_branch, node);
+        Plan<X> &plan = plans[(size_t)j];
+        if ((X::computed(dad_branch) & 1) == 0) collectPlan<X>(tree, dad_branch, dad, plan);
+        if ((X::computed(node_branch) & 1) == 0) collectPlan<X>(tree, node_branch, node, plan);
+        std::vector<int32_t> &lf = len_from[(size_t)j];
+        lf.assign(2 * plan.size(), -1);
+        for (size_t q = 0; q < lf.size(); q++)
+            for (size_t o = 0; o < opt_nb.size(); o++)
+                if (plan.len_nb[q] == opt_nb[o]) lf[q] = opt_step[o];
+        iqhip_sweep_step &st = steps[(size_t)j];
+        st.ops = plan.empty() ? (const iqhip_node_op *)0 : &plan.ops[0];
+        st.len_from = lf.empty() ? (const int32_t *)0 : &lf[0];
+        st.nops = (int32_t)plan.size();
+        st._pad = 0;
+        st.a = branchEnd<X>(node_branch);
+        st.b = branchEnd<X>(dad_branch);
+        st.xguess = X::length(it);
+        total_ops += plan.size();
+        opt_nb.push_back(it);
+        opt_step.push_back(j);
+        opt_nb.push_back(back);
+        opt_step.push_back(j);
+        /* optimizeOneBranch with clearLH and a changed length (phylotree.cpp:2186-2189) */
+        X::clearReversePartialLh(nodes1[j], nodes2[j]);
+        X::clearReversePartialLh(nodes2[j], nodes1[j]);
+    }
+    std::vector<double> sum_scale(total_ops + 1, 0.0);
+    std::vector<iqhip_branch_result> res((size_t)nbranches);
+    X::optimizeSweep(tree, &steps[0], nbranches, max_steps, diverge_frac, &sum_scale[0], &res[0]);
+    size_t off = 0;
+    int evals = 0;
+    for (int j = 0; j < nbranches; j++) {
+        applyScaleFactors<X>(plans[(size_t)j], &sum_scale[off]);
+        off += plans[(size_t)j].size();
+        X::setLength(X::findNeighbor(nodes1[j], nodes2[j]), res[(size_t)j].optx);
+        X::setLength(X::findNeighbor(nodes2[j], nodes1[j]), res[(size_t)j].optx);
+        evals += res[(size_t)j].nsteps;
+    }
+    X::setCurrent(tree, X::findNeighbor(nodes1[nbranches - 1], nodes2[nbranches - 1]),
+                  X::findNeighbor(nodes2[nbranches - 1], nodes1[nbranches - 1]));
+    X::thetaComputed(tree) = true;
+    if (nevals) *nevals = evals;
 }
 
 }  /* namespace iqhip_adapter */

@@ -164,6 +164,8 @@ struct HipPolicy : iqhip_adapter::EngineCalls<HipPolicy, PhyloTree> {
     static bool &thetaComputed(Tree *t) { return t->theta_computed; }
     static Neighbor *currentIt(Tree *t) { return t->current_it; }
     static Neighbor *currentItBack(Tree *t) { return t->current_it_back; }
+    static void clearReversePartialLh(Node *n, Node *dad) { n->clearReversePartialLh(dad); }
+    static void setCurrent(Tree *t, Neighbor *it, Neighbor *back) { t->current_it = it; t->current_it_back = back; }
     static double minBranchLength(Tree *t) { return t->params->min_branch_length; }
     static double maxBranchLength(Tree *t) { return t->params->max_branch_length; }
 };
@@ -195,6 +197,18 @@ double PhyloTree::computeLikelihoodFromBufferHIP() {
 //       optx = hipMinimizeNewton(current_len, maxNRStep); else ...        (+ASC keeps the host loop)
 double PhyloTree::hipMinimizeNewton(double current_len, int maxNRStep) {
     return iqhip_adapter::minimizeNewtonOnBranch<HipPolicy>(this, current_len, maxNRStep);
+}
+
+// Optional fast path for a whole sweep: the loop `for (j...) optimizeOneBranch(nodes1[j], nodes2[j], true, maxNRStep)` of
+// PhyloTree::optimizeAllBranches (phylotree.cpp:2285-2290) as ONE engine submission with one host round trip
+// (iqhip_optimize_sweep: per branch the pending node updates, theta, the whole minimizeNewton loop and the diverged-Newton
+// reset, later branches reading the lengths of earlier ones from device memory).  Hunk in optimizeAllBranches:
+//   if (optimize_by_newton && hip_engine && computePartialLikelihoodPointer == &PhyloTree::computePartialLikelihoodHIP
+//       && !isSuperTree()) hipOptimizeBranchSweep(nodes1, nodes2, maxNRStep); else for (j...) optimizeOneBranch(...);
+void PhyloTree::hipOptimizeBranchSweep(PhyloNodeVector &nodes1, PhyloNodeVector &nodes2, int maxNRStep) {
+    if (nodes1.empty()) return;
+    theta_computed = false;
+    iqhip_adapter::optimizeBranchSweep<HipPolicy>(this, &nodes1[0], &nodes2[0], (int)nodes1.size(), maxNRStep, 0.95);
 }
 
 // Lazy host views for the few callers that read kernel outputs on the host

@@ -34,7 +34,7 @@ IQHIP_SYMBOLS = [
     "iqhip_create_sharded", "iqhip_num_shards", "iqhip_shard_range", "iqhip_comm_unique_id", "iqhip_comm_init_rank",
     "iqhip_comm_size", "iqhip_update_partials_async", "iqhip_lnl_from_theta_async",
     "iqhip_newton_host_init", "iqhip_newton_host_update", "iqhip_newton_host_result",
-    "iqhip_debug_create_planner", "iqhip_debug_plan", "iqhip_timing_plan_bytes", "iqhip_timing_collective_read",
+    "iqhip_debug_create_planner", "iqhip_debug_plan", "iqhip_timing_plan_bytes", "iqhip_timing_collective_read", "iqhip_optimize_sweep",
 ]
 
 
@@ -172,6 +172,7 @@ def libiqhost():
     lib.iqhost_set_dry_run.argtypes = [vp, C.c_int]
     lib.iqhost_set_heavy_first.argtypes = [vp, C.c_int]
     lib.iqhost_set_device_newton.argtypes = [vp, C.c_int]
+    lib.iqhost_set_device_sweep.argtypes = [vp, C.c_int]
     lib.iqhost_num_derv_calls.argtypes = [vp]
     lib.iqhost_num_derv_calls.restype = C.c_long
     lib.iqhost_engine.argtypes = [vp]
@@ -384,6 +385,10 @@ class PhyloTree:
 
     def set_device_newton(self, on=True):
         self._chk(self.lib.iqhost_set_device_newton(self.h, int(on)))
+
+    def set_device_sweep(self, on=True):
+        """optimize_all_branches: every sweep as ONE engine submission (iqhip_optimize_sweep) instead of one per branch"""
+        self._chk(self.lib.iqhost_set_device_sweep(self.h, int(on)))
 
     @property
     def num_derv_calls(self):

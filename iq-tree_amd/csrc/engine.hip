@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <atomic>
@@ -236,10 +237,13 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
     void *ptrs[] = {e->d_states, e->d_freq, e->d_invar, e->d_model, e->d_ops, e->d_slab,
                     e->d_theta, e->d_pattern_lh, e->d_leaf_tab, e->dummy.plh, e->dummy.sc, e->d_newton_partials,
                     e->d_newton_barrier, e->d_newton_posts, e->d_fold_ticket, e->d_fold_flags, e->d_ptn_scaled, e->d_boot, e->d_img, e->d_theta_batch, e->d_batch_partials,
-                    e->d_batch_out, e->d_batch_barriers, e->d_batch_tasks, e->d_batch_posts};
+                    e->d_batch_out, e->d_batch_barriers, e->d_batch_tasks, e->d_batch_posts, e->d_sweep_len};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (e->h_ops) hipHostFree(e->h_ops);
+    if (e->h_sweep_desc) hipHostFree(e->h_sweep_desc);
+    if (e->d_sweep_desc) hipFree(e->d_sweep_desc);
+    if (e->d_sweep_posts) hipFree(e->d_sweep_posts);
     if (e->h_result) hipHostFree(e->h_result);
     if (e->h_done) hipHostFree((void *)e->h_done);
     if (e->staging_free) hipEventDestroy(e->staging_free);
@@ -770,8 +774,10 @@ static int check_plan(iqhip_engine *e, int nops, int nsentinels) {
     return IQHIP_OK;
 }
 
+// len_ptrs (sweeps): 2 * nops device pointers, [2k] / [2k+1] = where the length of op k's left / right child branch will
+// be found when the op runs (nullptr: the host value in the op)
 static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *last_dst,
-                      const std::vector<int> *explicit_segs = nullptr) {
+                      const std::vector<int> *explicit_segs = nullptr, const double *const *len_ptrs = nullptr) {
     constexpr int kSentinels = 2;  // >= the kernels' deepest look-ahead (streamed child: 1 op)
     if (nops + 2 > e->result_cap) return fail(IQHIP_ERR_INVALID, "too many node updates in one submission");
     // Same op list as last time and no key created / released / moved since: the descriptors on
@@ -779,7 +785,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
     const size_t in_bytes = sizeof(iqhip_node_op) * (size_t)nops;
     const std::vector<int> no_segs;
     const std::vector<int> &segs_in = explicit_segs ? *explicit_segs : no_segs;
-    if (nops > 0 && e->last_plan_version == e->keymap_version && e->last_ops_in.size() == in_bytes &&
+    if (!len_ptrs && nops > 0 && e->last_plan_version == e->keymap_version && e->last_ops_in.size() == in_bytes &&
         memcmp(e->last_ops_in.data(), ops, in_bytes) == 0 && !e->uploaded_plan.empty() && e->last_segs == segs_in) {
         *last_dst = e->last_plan_dst;
         return IQHIP_OK;
@@ -983,6 +989,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         if (lkind == CHILD_PREV && rkind == CHILD_PREV)
             return fail(IQHIP_ERR_INVALID, "node update uses the same vector for both children");
         double llen = o.left_len, rlen = o.right_len;
+        const double *llen_p = len_ptrs ? len_ptrs[2 * order[k]] : nullptr, *rlen_p = len_ptrs ? len_ptrs[2 * order[k] + 1] : nullptr;
         d.dst = e->slabs[didx].plh;
         d.dst_sc = e->slabs[didx].sc;
         if (e->mfma && !e->mfma_pipelined) {
@@ -995,7 +1002,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
             // them the previous result -- the kernel reads the second one synchronously.
             auto swap_children = [&]() {
                 std::swap(lp, rp); std::swap(lsc, rsc); std::swap(lst, rst);
-                std::swap(lkind, rkind); std::swap(llen, rlen);
+                std::swap(lkind, rkind); std::swap(llen, rlen); std::swap(llen_p, rlen_p);
             };
             if (lkind == CHILD_PREV) swap_children();                              // PREV goes right
             else if (lkind == CHILD_LEAF && rkind == CHILD_LOAD) swap_children();  // memory child goes left
@@ -1011,6 +1018,8 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         d.right_kind = rkind;
         d.left_len = llen;
         d.right_len = rlen;
+        d.left_len_p = llen_p;
+        d.right_len_p = rlen_p;
         prev_dst = didx;
     }
     // HOLD analysis (4-state kernel): a streamed left child produced by op j of this plan can stay
@@ -1060,7 +1069,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
     e->plan_tab_dirty = 0;
     if (e->mfma && e->mfma_pipelined && e->leaf_tables) {
         const size_t per = leaf_table_doubles(e);
-        struct Use { double len; int slot; };
+        struct Use { double len; const double *len_p; int slot; };
         std::unordered_map<int, std::vector<Use>> seen;  // taxon -> lengths used in this plan
         int noverflow = 0;
         std::vector<TabJob> dirty, clean;
@@ -1073,18 +1082,21 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
                 if ((side ? d.right_kind : d.left_kind) != CHILD_LEAF) continue;
                 const uint8_t *row = side ? d.sr : d.sl;
                 const int taxon = (int)((row - e->d_states) / e->nptn_pad);
-                const double len = side ? d.right_len : d.left_len;
+                const double *len_p = side ? d.right_len_p : d.left_len_p;   // (sweeps: the length is on the device)
+                const double len = len_p ? NAN : (side ? d.right_len : d.left_len);
                 std::vector<Use> &u = seen[taxon];
                 int slot = -1;
                 for (const Use &x : u)
-                    if (x.len == len) slot = x.slot;
+                    if (x.len_p == len_p && (len_p || x.len == len)) slot = x.slot;
                 if (slot < 0) {
                     slot = u.empty() ? taxon : e->ntaxa + noverflow++;
-                    u.push_back({len, slot});
+                    u.push_back({len, len_p, slot});
                     TabJob j;
                     j.len = len;
+                    j.len_p = len_p;
+                    j._pad = 0.0;
                     j.tab = reinterpret_cast<double *>((size_t)slot);  // slot number for now
-                    const bool cached = slot < e->ntaxa && !model_changed && (size_t)slot < e->tab_len.size() &&
+                    const bool cached = !len_p && slot < e->ntaxa && !model_changed && (size_t)slot < e->tab_len.size() &&
                                         e->tab_len[slot] == len;
                     (cached ? clean : dirty).push_back(j);
                 }
@@ -1208,7 +1220,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
     const size_t nbytes = sizeof(DevOp) * (size_t)(nops + kSentinels + table_ops + jobs_ops);
     e->last_ops_in.assign((const char *)ops, (const char *)ops + in_bytes);
     e->last_segs = segs_in;
-    e->last_plan_version = e->keymap_version;  // (slabs created while building are included)
+    e->last_plan_version = len_ptrs ? 0 : e->keymap_version;  // (slabs created while building are included; a sweep step's plan is never re-used)
     e->last_plan_dst = prev_dst;
     // a small plan of the 4-state kernel rides in the kernel arguments (launch_traverse4 copies it out of h_ops)
     // (matrix-core path: the pipelined 20-state kernels without leaf tables -- tables come with a job list in the buffer)
@@ -1275,12 +1287,12 @@ static void timing_end(iqhip_engine *e) {
 // enqueue: plan upload, K1, fused traversal (+ optional root lnL), fixed-order reduction
 static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, bool has_root,
                            iqhip_branch_end a, iqhip_branch_end b, double len, bool skip_reduce = false,
-                           const std::vector<int> *explicit_segs = nullptr) {
+                           const std::vector<int> *explicit_segs = nullptr, const double *const *len_ptrs = nullptr) {
     int rc = check_ready(e);
     if (rc) return rc;
     if (nops < 0 || (nops > 0 && !ops)) return fail(IQHIP_ERR_INVALID, "bad ops array");
     int last_dst = -1;
-    rc = build_plan(e, ops, nops, &last_dst, explicit_segs);
+    rc = build_plan(e, ops, nops, &last_dst, explicit_segs, len_ptrs);
     if (rc) return rc;
     DevBranch br;
     if (has_root) {
@@ -1754,6 +1766,289 @@ extern "C" int iqhip_optimize_branch(iqhip_engine *e, const iqhip_node_op *ops, 
     if (optx) *optx = r[0];
     if (d2l) *d2l = r[1];
     if (nsteps) *nsteps = (int)r[2];
+    return IQHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// A whole branch-length sweep -- PhyloTree::optimizeAllBranches' loop over optimizeOneBranch (phylotree.cpp:2252-2332,
+// 2148-2192) -- in ONE submission.  Step j = {the node updates that are pending at both ends of branch j, theta, the
+// Newton solve, the diverged-solve rule}; a child branch that an earlier step of the sweep optimised has its length read
+// from device memory (sweep_len[step]), where that step's Newton kernel left it, so nothing comes back to the host
+// between steps: 2 launches per step are enqueued back to back and the host reads one result block per sweep.
+// The caller builds the steps as if every step changed its branch (optimizeOneBranch's clearReversePartialLh on both
+// sides); a step that ends where it started only makes the later steps recompute vectors that were still valid.
+// ---------------------------------------------------------------------------------------
+static int sweep_resolve_ops(const iqhip_sweep_step &st, const iqhip_branch_result *results, std::vector<iqhip_node_op> &ops) {
+    ops.assign(st.ops, st.ops + st.nops);
+    if (st.len_from)
+        for (int k = 0; k < st.nops; k++) {
+            if (st.len_from[2 * k] >= 0) ops[k].left_len = results[st.len_from[2 * k]].optx;
+            if (st.len_from[2 * k + 1] >= 0) ops[k].right_len = results[st.len_from[2 * k + 1]].optx;
+        }
+    return IQHIP_OK;
+}
+
+// the same sweep one step at a time (a host round trip per step): sharded engines and engines with a communicator, where
+// every Newton step contains an all-reduce; +ASC; and the remainder of a sweep whose grid-wide exchange timed out
+static int sweep_sequential(iqhip_engine *e, const iqhip_sweep_step *steps, int first, int nsteps, double x1, double x2,
+                            double xacc, int max_steps, double diverge_frac, double *sum_scale, size_t ss_off,
+                            iqhip_branch_result *results) {
+    std::vector<iqhip_node_op> ops;
+    for (int j = first; j < nsteps; j++) {
+        const iqhip_sweep_step &st = steps[j];
+        sweep_resolve_ops(st, results, ops);
+        iqhip_branch_result &r = results[j];
+        r.status = 0;
+        r.lnl = 0.0;
+        int rc = iqhip_optimize_branch(e, ops.empty() ? nullptr : ops.data(), st.nops, st.a, st.b, st.xguess, x1, x2, xacc, max_steps,
+                                       sum_scale ? sum_scale + ss_off : nullptr, &r.optx, &r.d2l, &r.nsteps);
+        if (rc) return rc;
+        if (diverge_frac > 0.0 && r.optx > diverge_frac * x2) {   // phylotree.cpp:2167-2176
+            double opt_lh = 0.0, orig_lh = 0.0;
+            rc = iqhip_lnl_from_theta(e, r.optx, &opt_lh);
+            if (!rc) rc = iqhip_lnl_from_theta(e, st.xguess, &orig_lh);
+            if (rc) return rc;
+            if (orig_lh > opt_lh) r.optx = st.xguess;
+            r.status = 5;   // (informational: the rule was applied)
+        }
+        ss_off += (size_t)st.nops;
+    }
+    return IQHIP_OK;
+}
+
+// 4-state engines: the whole sweep as ONE launch of the persistent kernel k_sweep4 (kernels_sweep.hip) + one k_reduce for
+// the sum_scale rows; the host only resolves keys into descriptors, copies them down once and reads one result block
+static int sweep_persistent4(iqhip_engine *e, const iqhip_sweep_step *steps, int nsteps, size_t total_ops, double x1, double x2,
+                             double xacc, int max_steps, double diverge_frac, double *sum_scale, iqhip_branch_result *results) {
+    static const bool dbg = getenv("IQHIP_DEBUG_SWEEP") != nullptr;
+    timespec t0, t1, t2;
+    if (dbg) clock_gettime(CLOCK_MONOTONIC, &t0);
+    const size_t bytes_ops = sizeof(SweepOp) * total_ops, bytes_steps = sizeof(SweepStep) * (size_t)nsteps;
+    const size_t need = bytes_ops + bytes_steps;
+    if (need > e->sweep_desc_cap) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->h_sweep_desc) hipHostFree(e->h_sweep_desc);
+        if (e->d_sweep_desc) hipFree(e->d_sweep_desc);
+        e->h_sweep_desc = e->d_sweep_desc = nullptr;
+        e->sweep_desc_cap = 0;
+        const size_t cap = need * 2 + 4096;
+        HIPCHK(hipHostMalloc((void **)&e->h_sweep_desc, cap));
+        HIPCHK(hipMalloc((void **)&e->d_sweep_desc, cap));
+        e->sweep_desc_cap = cap;
+    }
+    SweepOp *hops = reinterpret_cast<SweepOp *>(e->h_sweep_desc);
+    SweepStep *hsteps = reinterpret_cast<SweepStep *>(e->h_sweep_desc + bytes_ops);
+    size_t row = 0;
+    for (int j = 0; j < nsteps; j++) {
+        const iqhip_sweep_step &st = steps[j];
+        SweepStep &hs = hsteps[j];
+        hs.op_begin = (int32_t)row;
+        hs.nops = st.nops;
+        hs.xguess = st.xguess;
+        for (int k = 0; k < st.nops; k++, row++) {
+            const iqhip_node_op &o = st.ops[k];
+            SweepOp &d = hops[row];
+            memset(&d, 0, sizeof d);
+            if (!(o.left_len >= 0.0) || !(o.right_len >= 0.0)) return fail(IQHIP_ERR_INVALID, "negative or NaN branch length");
+            const uint8_t *lst, *rst;
+            int32_t lk, rk;
+            int rc = resolve_child(e, o.left_key, o.left_leaf, -1, &d.lv, &d.lsc, &lst, &lk);
+            if (rc) return rc;
+            rc = resolve_child(e, o.right_key, o.right_leaf, -1, &d.rv, &d.rsc, &rst, &rk);
+            if (rc) return rc;
+            d.ls = lst ? lst : e->d_states;
+            d.rs = rst ? rst : e->d_states;
+            int didx;
+            rc = slab_for_key(e, o.dst_key, true, &didx);
+            if (rc) return rc;
+            d.dst = e->slabs[didx].plh;
+            d.dst_sc = e->slabs[didx].sc;
+            if (d.lv == d.dst || d.rv == d.dst) return fail(IQHIP_ERR_INVALID, "node update writes onto one of its own children");
+            d.llen = o.left_len;
+            d.rlen = o.right_len;
+            d.llen_step = st.len_from ? st.len_from[2 * k] : -1;
+            d.rlen_step = st.len_from ? st.len_from[2 * k + 1] : -1;
+            d.no_scale = (o.flags & IQHIP_OP_NO_SCALE) ? 1 : 0;
+            d.row = (int32_t)row;
+        }
+        int rc = build_branch(e, st.a, st.b, 0.0, -1, &hs.br);
+        if (rc) return rc;
+    }
+    const int grid = sweep4_grid(e), nwaves = grid * 4;
+    if ((int64_t)total_ops * nwaves > e->slab_cap) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->d_slab) hipFree(e->d_slab);
+        e->d_slab = nullptr;
+        e->slab_cap = 0;
+        HIPCHK(dmalloc(&e->d_slab, total_ops * (size_t)nwaves + 1024));
+        e->slab_cap = (int64_t)(total_ops * (size_t)nwaves + 1024);
+    }
+    const size_t posts_need = (size_t)2 * kNewtonPostEpochs * grid * 2;
+    if (posts_need > e->sweep_posts_cap) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->d_sweep_posts) hipFree(e->d_sweep_posts);
+        e->d_sweep_posts = nullptr;
+        e->sweep_posts_cap = 0;
+        HIPCHK(dmalloc(&e->d_sweep_posts, posts_need));
+        e->sweep_posts_cap = posts_need;
+    }
+    HIPCHK(hipMemcpyAsync(e->d_sweep_desc, e->h_sweep_desc, need, hipMemcpyHostToDevice, e->stream));
+    if (grid > 1) HIPCHK(hipMemsetAsync(e->d_sweep_posts, 0xFF, posts_need * sizeof(double), e->stream));
+    double *out = e->d_result + total_ops;      // (rows [0, total_ops) receive the sum_scale sums from k_reduce)
+    memset(e->h_result + total_ops, 0, sizeof(double) * 6 * (size_t)nsteps);
+    HIPCHK(launch_sweep4(e, reinterpret_cast<const SweepOp *>(e->d_sweep_desc),
+                         reinterpret_cast<const SweepStep *>(e->d_sweep_desc + bytes_ops), nsteps, x1, x2, xacc, max_steps,
+                         diverge_frac * x2, e->d_sweep_posts, out));
+    HIPCHK(launch_reduce(e, 0, (int)total_ops, nwaves));
+    const DevBranch &last = hsteps[nsteps - 1].br;
+    e->theta_valid = true;
+    e->theta_a_sc = last.a_sc;
+    e->theta_b_sc = last.b_sc;
+    e->last_plan_version = 0;
+    if (dbg) clock_gettime(CLOCK_MONOTONIC, &t1);
+    int rc = read_result(e, (int)(total_ops + 6 * (size_t)nsteps));
+    if (rc) return rc;
+    if (dbg) {
+        clock_gettime(CLOCK_MONOTONIC, &t2);
+        fprintf(stderr, "[iqhip] persistent sweep of %d steps (%zu node updates): descriptors + enqueue %.1f us, wait %.1f us\n", nsteps,
+                total_ops, (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3,
+                (t2.tv_sec - t1.tv_sec) * 1e6 + (t2.tv_nsec - t1.tv_nsec) * 1e-3);
+    }
+    if (sum_scale)
+        for (size_t k = 0; k < total_ops; k++) sum_scale[k] = e->h_result[k];
+    size_t ss = 0;
+    for (int j = 0; j < nsteps; j++) {
+        const double *o = e->h_result + total_ops + 6 * (size_t)j;
+        const int status = (int)o[3];
+        if (status == 2) return fail(IQHIP_ERR_INVALID, "Wrong computeFuncDerv (non-finite derivative)");
+        if (status == 3) return fail(IQHIP_ERR_INVALID, "Maximum number of iterations exceeded in minimizeNewton");
+        if (status == 4) {   // the exchange between the workgroups gave up: finish from here one step at a time
+            (void)hipStreamSynchronize(e->stream);
+            return sweep_sequential(e, steps, j, nsteps, x1, x2, xacc, max_steps, diverge_frac, sum_scale, ss, results);
+        }
+        results[j].optx = o[0];
+        results[j].d2l = o[1];
+        results[j].nsteps = (int)o[2];
+        results[j].status = o[4] != 0.0 ? 5 : 0;
+        results[j].lnl = 0.0;
+        ss += (size_t)steps[j].nops;
+    }
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_optimize_sweep(iqhip_engine *e, const iqhip_sweep_step *steps, int nsteps, double x1, double x2,
+                                    double xacc, int max_steps, double diverge_frac, double *sum_scale,
+                                    iqhip_branch_result *results) {
+    if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    if (!steps || !results || nsteps < 1) return fail(IQHIP_ERR_INVALID, "iqhip_optimize_sweep: bad step array");
+    if (!(x1 >= 0.0) || !(x2 > x1) || !(xacc > 0.0) || max_steps < 1 || !(diverge_frac >= 0.0) || diverge_frac >= 1.0)
+        return fail(IQHIP_ERR_INVALID, "iqhip_optimize_sweep: bad bounds / tolerance / step count");
+    size_t total_ops = 0;
+    for (int j = 0; j < nsteps; j++) {
+        const iqhip_sweep_step &st = steps[j];
+        if (st.nops < 0 || (st.nops > 0 && !st.ops)) return fail(IQHIP_ERR_INVALID, "bad ops array in a sweep step");
+        if (!(st.xguess >= 0.0)) return fail(IQHIP_ERR_INVALID, "iqhip_optimize_sweep: bad starting length");
+        if (st.len_from)
+            for (int q = 0; q < 2 * st.nops; q++)
+                if (st.len_from[q] >= j) return fail(IQHIP_ERR_INVALID, "a sweep step may only use the lengths of earlier steps");
+        total_ops += (size_t)st.nops;
+    }
+    static const bool one_submission = [] { const char *v = getenv("IQHIP_SWEEP"); return !v || atoi(v) != 0; }();
+    if (!e->shards.empty() || e->comm || e->n_unobs > 0 || !one_submission || newton_use_chain(e) ||
+        2 + total_ops + 6 * (size_t)nsteps > (size_t)e->result_cap || e->d_result != e->d_result_own)
+        return sweep_sequential(e, steps, 0, nsteps, x1, x2, xacc, max_steps, diverge_frac, sum_scale, 0, results);
+    int rc = check_ready(e);
+    if (rc) return rc;
+    static const bool persistent = [] { const char *v = getenv("IQHIP_SWEEP_KERNEL"); return !v || atoi(v) != 0; }();
+    if (persistent && !e->mfma && e->nclass == 1 && nsteps <= 4096 && max_steps + 5 <= kNewtonPostEpochs && total_ops > 0)
+        return sweep_persistent4(e, steps, nsteps, total_ops, x1, x2, xacc, max_steps, diverge_frac, sum_scale, results);
+    if (nsteps > e->sweep_len_cap) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->d_sweep_len) hipFree(e->d_sweep_len);
+        e->d_sweep_len = nullptr;
+        e->sweep_len_cap = 0;
+        HIPCHK(dmalloc(&e->d_sweep_len, (size_t)nsteps + 64));
+        e->sweep_len_cap = nsteps + 64;
+    }
+    static const bool dbg = getenv("IQHIP_DEBUG_SWEEP") != nullptr;
+    double t_trav = 0.0, t_newt = 0.0;
+    timespec ts0;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    // result block in the (host-mapped) result vector: per step its sum_scale rows, then {optx, d2l, nsteps, status, diverged, -}
+    std::vector<size_t> row_of(nsteps);
+    size_t row = 2;
+    std::vector<const double *> len_ptrs;
+    iqhip_branch_end none = {0, -1, 0};
+    for (int j = 0; j < nsteps; j++) {
+        const iqhip_sweep_step &st = steps[j];
+        row_of[j] = row;
+        if (st.nops > 0) {
+            const double *const *lp = nullptr;
+            if (st.len_from) {
+                len_ptrs.assign((size_t)2 * st.nops, nullptr);
+                bool any = false;
+                for (int q = 0; q < 2 * st.nops; q++)
+                    if (st.len_from[q] >= 0) { len_ptrs[q] = e->d_sweep_len + st.len_from[q]; any = true; }
+                if (any) lp = len_ptrs.data();
+            }
+            timespec ta, tb;
+            if (dbg) clock_gettime(CLOCK_MONOTONIC, &ta);
+            rc = submit_traverse(e, st.ops, st.nops, false, none, none, 0.0, /*skip_reduce=*/true, nullptr, lp);
+            if (rc) return rc;
+            if (dbg) { clock_gettime(CLOCK_MONOTONIC, &tb); t_trav += (tb.tv_sec - ta.tv_sec) * 1e6 + (tb.tv_nsec - ta.tv_nsec) * 1e-3; }
+        }
+        DevBranch br;
+        rc = build_branch(e, st.a, st.b, 0.0, -1, &br);
+        if (rc) return rc;
+        e->theta_valid = true;
+        e->theta_a_sc = br.a_sc;
+        e->theta_b_sc = br.b_sc;
+        NewtonSweepStep sw;
+        sw.len_out = e->d_sweep_len + j;
+        sw.rows_base = e->d_result + row;
+        sw.diverge_x = diverge_frac * x2;
+        sw.publish = (j == nsteps - 1);
+        timespec tc, td;
+        if (dbg) clock_gettime(CLOCK_MONOTONIC, &tc);
+        HIPCHK(launch_newton(e, st.xguess, x1, x2, xacc, max_steps, e->d_result + row + st.nops, &br, st.nops,
+                             (int)e->ntiles * e->lane_split, &sw));
+        if (dbg) { clock_gettime(CLOCK_MONOTONIC, &td); t_newt += (td.tv_sec - tc.tv_sec) * 1e6 + (td.tv_nsec - tc.tv_nsec) * 1e-3; }
+        row += (size_t)st.nops + 6;
+    }
+    timespec ts1;
+    if (dbg) clock_gettime(CLOCK_MONOTONIC, &ts1);
+    rc = read_result(e, (int)row);
+    if (rc) return rc;
+    if (dbg) {
+        timespec ts2;
+        clock_gettime(CLOCK_MONOTONIC, &ts2);
+        fprintf(stderr, "[iqhip] sweep of %d steps: submit_traverse %.1f us, launch_newton %.1f us; enqueue %.1f us, wait %.1f us\n", nsteps, t_trav, t_newt,
+                (ts1.tv_sec - ts0.tv_sec) * 1e6 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-3,
+                (ts2.tv_sec - ts1.tv_sec) * 1e6 + (ts2.tv_nsec - ts1.tv_nsec) * 1e-3);
+    }
+    size_t ss = 0;
+    for (int j = 0; j < nsteps; j++) {
+        const iqhip_sweep_step &st = steps[j];
+        const double *r = e->h_result + row_of[j];
+        if (sum_scale)
+            for (int k = 0; k < st.nops; k++) sum_scale[ss + k] = r[k];
+        const double *o = r + st.nops;
+        const int status = (int)o[3];
+        if (status == 2) return fail(IQHIP_ERR_INVALID, "Wrong computeFuncDerv (non-finite derivative)");
+        if (status == 3) return fail(IQHIP_ERR_INVALID, "Maximum number of iterations exceeded in minimizeNewton");
+        if (status == 4) {
+            // the grid-wide exchange of this step's solve gave up (another kernel held the CUs): its length and everything
+            // after it is void -- finish the sweep from here one step at a time (the chain form needs no co-residency)
+            (void)hipStreamSynchronize(e->stream);
+            return sweep_sequential(e, steps, j, nsteps, x1, x2, xacc, max_steps, diverge_frac, sum_scale, ss, results);
+        }
+        results[j].optx = o[0];
+        results[j].d2l = o[1];
+        results[j].nsteps = (int)o[2];
+        results[j].status = o[4] != 0.0 ? 5 : 0;
+        results[j].lnl = 0.0;
+        ss += (size_t)st.nops;
+    }
     return IQHIP_OK;
 }
 

@@ -59,7 +59,21 @@ struct __attribute__((aligned(16))) DevOp {
     // image, see kernels_mfma.hip leaf_tab_pos); dummy-valid for non-leaf children
     const double *tabL;
     const double *tabR;
+    // branch-length sweeps (iqhip_optimize_sweep): a child branch whose length is the result of an earlier step of the
+    // same submission is read from device memory when the op runs (written there by that step's Newton solve);
+    // nullptr: the host value left_len / right_len
+    const double *left_len_p;
+    const double *right_len_p;
 };
+
+#if defined(__HIPCC__)
+// length of a child branch of a node update: the host value, or the result of an earlier step of a sweep
+template <typename OpRef>
+__device__ __forceinline__ double op_child_len(const OpRef &d, int child) {
+    const double *p = child ? d.right_len_p : d.left_len_p;
+    return p ? *p : (child ? d.right_len : d.left_len);
+}
+#endif
 
 // Root branch descriptor for the lnL / theta kernels.
 struct __attribute__((aligned(16))) DevBranch {
@@ -73,6 +87,24 @@ struct __attribute__((aligned(16))) DevBranch {
     double len;
 };
 
+// one node update / one step of a persistent branch-length sweep (kernels_sweep.hip k_sweep4)
+struct __attribute__((aligned(16))) SweepOp {
+    double *dst;
+    int16_t *dst_sc;
+    const double *lv, *rv;      // child vectors; nullptr: the child is a leaf
+    const int16_t *lsc, *rsc;
+    const uint8_t *ls, *rs;     // state rows of leaf children
+    double llen, rlen;
+    int32_t llen_step, rlen_step;  // >= 0: the child branch's length is the one that step of this sweep accepted
+    int32_t no_scale;
+    int32_t row;                // row of the wave-partial slab / of the caller's concatenated sum_scale array
+};
+struct __attribute__((aligned(16))) SweepStep {
+    DevBranch br;
+    double xguess;
+    int32_t op_begin, nops;
+};
+
 struct Slab {
     double *plh = nullptr;
     int16_t *sc = nullptr;
@@ -81,6 +113,8 @@ struct Slab {
 struct __attribute__((aligned(16))) TabJob {  // one K2 table to build: tab[c][state][pos(x)] for branch length len
     double len;
     double *tab;
+    const double *len_p;   // non-null: the length is read from device memory (sweeps), `len` is ignored
+    double _pad;
 };
 
 // Optimization::minimizeNewton (optimization.cpp:388-465) as a state machine that is advanced once per derivative
@@ -300,6 +334,13 @@ struct iqhip_engine {
     size_t theta_batch_cap = 0;
     int batch_cap = 0;
     unsigned int batch_launches = 0;
+    double *d_sweep_len = nullptr;   // iqhip_optimize_sweep: the accepted length of every step, read by later steps' node updates
+    int sweep_len_cap = 0;
+    // ... persistent form (4 states): descriptors of all steps (pinned staging + device copy) and the exchange slots
+    char *h_sweep_desc = nullptr, *d_sweep_desc = nullptr;
+    size_t sweep_desc_cap = 0;
+    double *d_sweep_posts = nullptr;
+    size_t sweep_posts_cap = 0;
     int num_cus = 256;
     int result_cap = 0;
     // ---- collectives (comm.hip).  comm != nullptr: this engine is one rank of a pattern-sharded run; every
@@ -550,15 +591,29 @@ hipError_t launch_reduce(iqhip_engine *e, int first_row, int nrows, int nwaves);
 // kernels_newton.hip
 // build_from != nullptr: the first evaluation also builds theta from that branch; reduce_rows > 0: the
 // sum_scale rows [2, 2 + reduce_rows) of the slab are summed into the result vector first
+// sweep != nullptr (one step of iqhip_optimize_sweep): the accepted length also goes to *len_out (device memory read by
+// later steps), the sum_scale rows go to rows_base[0 .. reduce_rows) instead of result[2 ..], the diverged-solve rule is
+// applied on the device above diverge_x, and only the step with `publish` signals the polling host
+struct NewtonSweepStep {
+    double *len_out;
+    double *rows_base;
+    double diverge_x;
+    bool publish;
+};
 hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps,
                          double *out, const DevBranch *build_from = nullptr, int reduce_rows = 0,
-                         int reduce_nwaves = 0);
+                         int reduce_nwaves = 0, const NewtonSweepStep *sweep = nullptr);
 
 // Newton as a chain of enqueued steps (kernels_newton.hip): state init, derivative evaluation at state->rts
 // (skipped once state->done), state update from result[0..1]
 hipError_t launch_newton_state_init(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps);
 hipError_t launch_derv_at_state(iqhip_engine *e, int nwaves);
 hipError_t launch_newton_state_update(iqhip_engine *e);
+
+// kernels_sweep.hip: a whole sweep of a 4-state engine in one launch; posts: [2][kNewtonPostEpochs][grid][2] all-ones
+int sweep4_grid(const iqhip_engine *e);
+hipError_t launch_sweep4(iqhip_engine *e, const SweepOp *d_ops, const SweepStep *d_steps, int nsteps, double x1, double x2,
+                         double xacc, int max_steps, double diverge_x, double *posts, double *out);
 
 // kernels_rell.hip
 hipError_t launch_pattern_lh_scaled(iqhip_engine *e, const int16_t *sc_a, const int16_t *sc_b, double *out);

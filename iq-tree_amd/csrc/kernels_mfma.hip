@@ -238,7 +238,7 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
         for (int t = threadIdx.x; t < kn * 2 * B; t += WG) {
             const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B;
             const CONST_AS DevOp &d = as_const(A.ops)[k + o];
-            const double len = child ? d.right_len : d.left_len;
+            const double len = op_child_len(d, child);
             sReg[(child ? d.lds_right : d.lds_left) + e] = exp(A.evalc[e] * (A.rates[e / N] * len));
         }
         __syncthreads();
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void k_leaf_tables(const TabJob *jobs, int nca
     __shared__ double s_ex[N];
     extern __shared__ __attribute__((aligned(16))) double s_tip[];  // [rows of this block][N]
     const int job = blockIdx.x / (ncat * nsplit), r = blockIdx.x - job * ncat * nsplit, c = r / nsplit, sp = r - c * nsplit;
-    const double len = jobs[job].len;
+    const double len = jobs[job].len_p ? *jobs[job].len_p : jobs[job].len;
     double *tab = jobs[job].tab + (size_t)c * nstate_rows * N;
     const int per = (nstate_rows + nsplit - 1) / nsplit, s_lo = sp * per, s_hi = min(nstate_rows, s_lo + per);
     if (threadIdx.x < N) s_ex[threadIdx.x] = exp(eval[threadIdx.x] * (rates[c] * len));
@@ -558,7 +558,7 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
             const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B;
             const CONST_AS DevOp &d = ops[k + o];
             if (TAB && (child ? d.right_kind : d.left_kind) == CHILD_LEAF) continue;  // a table child needs no exponentials
-            const double len = child ? d.right_len : d.left_len;
+            const double len = op_child_len(d, child);
             sReg[(child ? d.lds_right : d.lds_left) + e] = exp(A.eval[e % N] * (A.rates[e / N] * len));
         }
         if constexpr (TABL) {
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_mix20(const TravMArgs A
         for (int t = threadIdx.x; t < kn * 2 * B; t += WG) {
             const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B;
             const CONST_AS DevOp &d = ops[k + o];
-            const double len = child ? d.right_len : d.left_len;
+            const double len = op_child_len(d, child);
             sReg[(child ? d.lds_right : d.lds_left) + e] = exp(A.evalc[e] * (A.rates[e / N] * len));
         }
         __syncthreads();
@@ -1143,7 +1143,7 @@ __device__ __forceinline__ void trav_rows64_body(const TravMArgs &A, const int v
         for (int t = threadIdx.x; t < kn * 2 * B; t += WG) {
             const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B;
             const CONST_AS DevOp &d = ops[k + o];
-            const double len = child ? d.right_len : d.left_len;
+            const double len = op_child_len(d, child);
             sReg[(child ? d.lds_right : d.lds_left) + e] = exp(A.eval[e] * (A.rates[0] * len));
         }
         __syncthreads();

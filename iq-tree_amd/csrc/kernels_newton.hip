@@ -87,6 +87,12 @@ struct NewtonArgs {
     int n, ncat, mfma;
     double xguess, x1, x2, xacc;
     int max_steps;
+    // branch-length sweeps (iqhip_optimize_sweep): the accepted length also goes to device memory, where the node
+    // updates of the later steps of the same submission read it (DevOp::left_len_p / right_len_p)
+    double *len_out;
+    // > 0: PhyloTree::optimizeOneBranch's "newton raphson diverged, reset" rule (phylotree.cpp:2167-2176) applied here:
+    // a result above this length is kept only if the branch lnL there is not below the lnL at the starting length
+    double diverge_x;
 };
 
 // sum over the four lane groups of a pattern (lanes p, p+16, p+32, p+48) with gfx950's permlane swaps instead of
@@ -351,6 +357,78 @@ __global__ __launch_bounds__(256) void k_newton(const NewtonArgs A) {
         df = -pddf;
     };
 
+    // sum over all patterns of f * log|lh_ptn| at branch length x (computeLikelihoodFromBuffer's sum, phylokernel.h:1040-1099),
+    // exchanged like the derivative sums; only the diverged-solve rule below needs it
+    auto lnl_at = [&](double x) -> double {
+        for (int t = threadIdx.x; t < B; t += 256) {
+            const int c = t / A.n;
+            const double cof = A.eval[t] * A.rates[c];
+            const double v = exp(cof * x) * A.props[c];
+            s_v0[t] = v;
+            s_v1[t] = cof * v;
+            s_v2[t] = cof * (cof * v);
+        }
+        __syncthreads();
+        double p0, p1;
+        wg_partial<false, 1>(A, A.theta, A.br, blockIdx.x, gridDim.x, s_v0, s_v1, s_v2, s_red, p0, p1);
+        if (gridDim.x > 1 && A.posts) {
+            unsigned long long *slots = reinterpret_cast<unsigned long long *>(A.posts) + (size_t)epoch * gridDim.x * 2;
+            if (threadIdx.x == 0) {
+                unsigned long long ua = __double_as_longlong(p0);
+                if (ua == ~0ull) ua = 0x7ff8000000000000ull;
+                __hip_atomic_store(&slots[2 * blockIdx.x], ua, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (threadIdx.x < 64) {
+                double a = 0.0;
+                long spins = 0;
+                for (;;) {
+                    bool ready = true;
+                    a = 0.0;
+                    for (int w = threadIdx.x; w < (int)gridDim.x; w += 64) {
+                        const unsigned long long ua = __hip_atomic_load(&slots[2 * w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ready = ready && ua != ~0ull;
+                        a += __longlong_as_double(ua);
+                    }
+                    if (__all(ready)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > 2000000L) { if (threadIdx.x == 0) s_fail = 1; break; }
+                }
+                a = wsum(a);
+                if (threadIdx.x == 0) s_bcast[0] = a;
+            }
+            __syncthreads();
+            p0 = s_bcast[0];
+            __syncthreads();
+            epoch++;
+        } else if (gridDim.x > 1) {
+            double *slot = A.partials + (size_t)(epoch & 1) * gridDim.x * 2;
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(&slot[2 * blockIdx.x], p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(A.barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int target = (epoch + 1) * gridDim.x;
+                long spins = 0;
+                while (__hip_atomic_load(A.barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > 4000000L) { s_fail = 1; break; }
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                double a = 0.0;
+                for (int w = threadIdx.x; w < (int)gridDim.x; w += 64)
+                    a += __hip_atomic_load(&slot[2 * w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a = wsum(a);
+                if (threadIdx.x == 0) s_bcast[0] = a;
+            }
+            __syncthreads();
+            p0 = s_bcast[0];
+            __syncthreads();
+            epoch++;
+        }
+        return p0;
+    };
+
     // ---- Optimization::minimizeNewton (optimization.cpp:388-450), same control flow
     double df, dx, f, temp, xh, xl, rts, rts_old, d2l;
     int nsteps = 1, status = 0;
@@ -390,6 +468,15 @@ __global__ __launch_bounds__(256) void k_newton(const NewtonArgs A) {
         }
         if (j > A.max_steps) status = 3;  // "Maximum number of iterations exceeded"
     }
+    // "newton raphson diverged, reset" (phylotree.cpp:2167-2176): opt_lh at the result against orig_lh at the starting
+    // length, both computeLikelihoodFromBuffer sums of this branch (their lh_scale_factor terms are the same)
+    double diverged = 0.0;
+    if (A.diverge_x > 0.0 && status == 0 && result > A.diverge_x) {
+        const double opt_lh = lnl_at(result);
+        const double orig_lh = lnl_at(A.xguess);
+        diverged = 1.0;
+        if (orig_lh > opt_lh) result = A.xguess;
+    }
     __syncthreads();
     if (s_fail) status = 4;  // grid barrier timed out
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -397,6 +484,8 @@ __global__ __launch_bounds__(256) void k_newton(const NewtonArgs A) {
         A.out[1] = d2l;
         A.out[2] = (double)nsteps;
         A.out[3] = (double)status;
+        if (A.diverge_x > 0.0) A.out[4] = diverged;
+        if (A.len_out) *A.len_out = result;
         if (A.done) {
             __threadfence_system();
             *A.done = A.seq;
@@ -714,13 +803,16 @@ hipError_t launch_newton_state_update(iqhip_engine *e) {
 }
 
 hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps,
-                         double *out, const DevBranch *build_from, int reduce_rows, int reduce_nwaves) {
+                         double *out, const DevBranch *build_from, int reduce_rows, int reduce_nwaves,
+                         const NewtonSweepStep *sweep) {
     NewtonArgs A;
+    A.len_out = sweep ? sweep->len_out : nullptr;
+    A.diverge_x = sweep ? sweep->diverge_x : 0.0;
     A.build = build_from ? 1 : 0;
     A.br = build_from ? *build_from : DevBranch{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.0};
     A.tipc = e->d_tipc;
     A.slab = e->d_slab;
-    A.result = e->d_result;
+    A.result = sweep ? sweep->rows_base - 2 : e->d_result;   // (row r of the node updates goes to result[2 + r])
     A.nrows = reduce_rows;
     A.nwaves = reduce_nwaves;
     A.theta = e->d_theta;
@@ -744,7 +836,7 @@ hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, d
     // every workgroup must be resident for the exchange: one per CU with the arrival counter (its slots are sized for that),
     // two per CU with the posted exchange (125 registers, little LDS: four would fit), so that a 100 k-pattern alignment
     // has one tile per wave and a derivative pass is one round trip
-    const bool posts = e->newton_posts && max_steps + 3 <= kNewtonPostEpochs;
+    const bool posts = e->newton_posts && max_steps + 5 <= kNewtonPostEpochs;   // (+2: the lnL passes of the diverged-solve rule)
     const int64_t wgs = (e->ntiles + 3) / 4;
     const int64_t max_grid = posts ? 2 * (int64_t)e->num_cus : e->num_cus;
     int grid = (int)(wgs < 1 ? 1 : (wgs > max_grid ? max_grid : wgs));
@@ -755,7 +847,8 @@ hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, d
     A.seq = 0;
     // (a single workgroup reduces all rows itself; several need the posted exchange in between -- the counter form
     // gives the same ordering, the rows are written before the workgroup's first arrival)
-    if (e->poll_result && e->d_result == e->d_result_own && out >= e->d_result && out < e->d_result + e->result_cap) {
+    if ((!sweep || sweep->publish) && e->poll_result && e->d_result == e->d_result_own && out >= e->d_result &&
+        out < e->d_result + e->result_cap) {
         A.seq = ++e->result_seq;
         A.done = e->d_done;
         e->poll_pending = true;

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
         for (int t = threadIdx.x; t < kn * 2 * B; t += WG) {  // phase 1: exponentials
             const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B;
             const CONST_AS DevOp &d = ops[k + o];
-            const double len = child ? d.right_len : d.left_len;
+            const double len = op_child_len(d, child);
             s_reg[(child ? d.lds_right : d.lds_left) + e] = exp(A.eval[e & 3] * (A.rates[e >> 2] * len));
         }
         __syncthreads();

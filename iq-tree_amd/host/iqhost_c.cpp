@@ -79,6 +79,7 @@ int iqhost_attach_comm(void *h, int nranks, int rank, const void *unique_id) {
     IQHOST_TRY(((PhyloTree *)h)->attachComm(nranks, rank, unique_id));
 }
 int iqhost_set_device_newton(void *h, int on) { IQHOST_TRY(((PhyloTree *)h)->device_newton = on != 0); }
+int iqhost_set_device_sweep(void *h, int on) { IQHOST_TRY(((PhyloTree *)h)->device_sweep = on != 0); }
 long iqhost_num_derv_calls(void *h) { return ((PhyloTree *)h)->num_derv_calls; }
 int iqhost_set_heavy_first(void *h, int on) { IQHOST_TRY(((PhyloTree *)h)->heavy_first = on != 0); }
 int iqhost_set_dry_run(void *h, int on) { IQHOST_TRY(((PhyloTree *)h)->setDryRun(on != 0)); }

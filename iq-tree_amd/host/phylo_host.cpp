@@ -1,5 +1,6 @@
 // phylo_host.cpp -- see phylo_host.h.  Host logic only; all arithmetic on partial-likelihood
 // vectors happens in libiqhip.so.
+#include <time.h>
 #include "phylo_host.h"
 
 #include <assert.h>
@@ -523,6 +524,13 @@ struct MirrorPolicy : iqhip_adapter::EngineCalls<MirrorPolicy, PhyloTree> {
     static bool &thetaComputed(Tree *t) { return t->theta_computed; }
     static Neighbor *currentIt(Tree *t) { return t->current_it; }
     static Neighbor *currentItBack(Tree *t) { return t->current_it_back; }
+    static void clearReversePartialLh(Node *n, Node *dad) { n->clearReversePartialLh(dad); }
+    static void setCurrent(Tree *t, Neighbor *it, Neighbor *back) { t->current_it = it; t->current_it_back = back; }
+    static void optimizeSweep(Tree *t, const iqhip_sweep_step *steps, int nsteps, int max_steps, double diverge_frac,
+                              double *sum_scale, iqhip_branch_result *results) {
+        needEngine(t);
+        Base::optimizeSweep(t, steps, nsteps, max_steps, diverge_frac, sum_scale, results);
+    }
     static double minBranchLength(Tree *t) { return t->min_branch_length; }
     static double maxBranchLength(Tree *t) { return t->max_branch_length; }
 
@@ -757,7 +765,24 @@ double PhyloTree::optimizeAllBranches(int my_iterations, double tolerance, int m
     for (int i = 0; i < my_iterations; i++) {
         std::vector<double> lenvec;
         for (PhyloNeighbor *nb : all_neighbors) lenvec.push_back(nb->length);
-        for (size_t j = 0; j < nodes1.size(); j++) optimizeOneBranch(nodes1[j], nodes2[j], true, maxNRStep);
+        if (device_sweep && device_newton && engine && !dry_run && !allreduce_hook && n_unobserved == 0) {
+            // the whole loop as one engine submission (iqhip_adapter::optimizeBranchSweep -> iqhip_optimize_sweep)
+            theta_computed = false;
+            int nevals = 0;
+            timespec ts0, ts1;
+            static const bool dbg = getenv("IQHIP_DEBUG_SWEEP") != nullptr;
+            if (dbg) clock_gettime(CLOCK_MONOTONIC, &ts0);
+            iqhip_adapter::optimizeBranchSweep<MirrorPolicy>(this, nodes1.data(), nodes2.data(), (int)nodes1.size(), maxNRStep,
+                                                            0.95, &nevals);
+            if (dbg) {
+                clock_gettime(CLOCK_MONOTONIC, &ts1);
+                fprintf(stderr, "[iqhost] optimizeBranchSweep: %.1f us in all\n", (ts1.tv_sec - ts0.tv_sec) * 1e6 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-3);
+            }
+            num_derv_calls += nevals;
+            num_submissions++;
+        } else {
+            for (size_t j = 0; j < nodes1.size(); j++) optimizeOneBranch(nodes1[j], nodes2[j], true, maxNRStep);
+        }
         double new_tree_lh = computeLikelihoodFromBuffer();
         if (new_tree_lh < tree_lh) {  // rare: restore and stop (phylotree.cpp:2303-2319)
             clearAllPartialLH();

@@ -135,6 +135,7 @@ public:
     // optimizeOneBranch: run the whole Newton-Raphson solve on the device (iqhip_newton_branch)
     // instead of one computeLikelihoodDerv round trip per step; off -> the reference's host loop
     bool device_newton = true;
+    bool device_sweep = true;   // optimizeAllBranches: a whole sweep as one engine submission (iqhip_optimize_sweep)
     long num_derv_calls = 0;  // derivative evaluations (host loop: calls; device loop: reported steps)
     iqhip_engine *engine = nullptr;
     // Pattern-sharded runs (one process per GPU): when set, every host-visible result vector

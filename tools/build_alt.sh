@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 d=iq-tree_amd/lib_alt_$name
 mkdir -p $d
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-value -Wno-unused-result -Iinclude"
-for f in engine kernels_valu4 kernels_mfma kernels_newton kernels_rell comm sharded; do
+for f in engine kernels_valu4 kernels_mfma kernels_newton kernels_sweep kernels_rell comm sharded; do
   case $f in
     kernels_mfma|kernels_valu4) /opt/rocm/bin/hipcc $FLAGS "$@" -c iq-tree_amd/csrc/$f.hip -o $d/$f.o & ;;
     *) cp iq-tree_amd/lib/$f.o $d/$f.o ;;

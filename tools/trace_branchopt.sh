@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel timeline of one optimizeAllBranches sweep (device Newton), DNA 50 x 100k
 set -e
-OUT=$GRAFT_REPO_ROOT/gpurun_out/trace_bo
+OUT=$GRAFT_REPO_ROOT/gpurun_out/trace_bo_${1:-100000}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cat > /tmp/bo.py <<'PY'
@@ -13,7 +13,7 @@ model = synth.gtr_model()
 nwk, pat, freq = synth.make_workload(50, int(sys.argv[1]), model, seed=3)
 t = pkg.PhyloTree(nwk); t.set_alignment(4, 0, pat, freq); t.set_model(model); t.attach_engine(0)
 t.clear_all_partial_lh(); t.compute_likelihood()
-t.optimize_all_branches(iterations=1, tolerance=1e-3)
+t.optimize_all_branches(iterations=1, tolerance=1e-3)   # (one engine submission per sweep: iqhip_optimize_sweep)
 PY
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 /tmp/bo.py ${1:-100000} > $OUT/run.log 2>&1
 python3 - "$OUT" <<'PY'
