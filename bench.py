@@ -354,6 +354,50 @@ def run_workload(args, D, pkg, synth, workload, steps, warmup, with_cpu_baseline
     return out
 
 
+def run_branchopt(pkg, synth, shapes=((50, 100000), (44, 355))):
+    """Hot loop 2: one optimizeAllBranches sweep (phylotree.cpp:2252-2332) over all 2T-3 branches of
+    a DNA GTR+G4 tree, every branch starting at 0.1 -- as one engine submission per branch (iqhip_optimize_branch) and as
+    ONE submission per sweep (iqhip_optimize_sweep: a persistent kernel for 4-state engines).  us per branch, and the
+    fraction of the HBM peak that the bytes a branch cannot avoid (two node updates of three vectors each, theta written
+    once, read once per derivative evaluation) amount to at that speed."""
+    model = synth.gtr_model()
+    out = []
+    for (T, P) in shapes:
+        nwk, pat, freq = synth.make_workload(T, P, model, seed=3)
+        row = {"ntaxa": T, "patterns": P, "model": "GTR+G4", "branches": 2 * T - 3}
+        for form in ("branch", "sweep"):
+            t = pkg.PhyloTree(nwk)
+            t.set_alignment(4, pkg.SEQ_DNA, pat, freq)
+            t.set_model(model)
+            t.attach_engine(0)
+            t.set_device_newton(True)
+            t.set_device_sweep(form == "sweep")
+            best = None
+            for rep in range(4):   # (the first repetition pays allocations)
+                for a in range(t.num_nodes):
+                    for b, _ in t.neighbors(a):
+                        if a < b:
+                            t.set_branch_length(a, b, 0.1, clear_reverse=False)
+                t.clear_all_partial_lh()
+                t.compute_likelihood()
+                c0, t0 = t.num_derv_calls, time.perf_counter()
+                lnl = t.optimize_all_branches(iterations=1, tolerance=1e-3)
+                dt = time.perf_counter() - t0
+                if best is None or dt < best[0]:
+                    best = (dt, t.num_derv_calls - c0, lnl)
+            t.close()
+            dt, nev, lnl = best
+            nb = 2 * T - 3
+            V = P * 16 * 8.0
+            stream_bytes = 6 * V + V + (nev / nb) * V
+            us = dt * 1e6 / nb
+            row[form] = {"us_per_branch": us, "sweep_ms": dt * 1e3, "derivative_evaluations": nev, "lnL": lnl,
+                         "hbm_frac": stream_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+        row["unavoidable_bytes_per_branch"] = 6 * V + V + (row["sweep"]["derivative_evaluations"] / (2 * T - 3)) * V
+        out.append(row)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -408,6 +452,8 @@ def main():
             r.pop("sustained", None)
             also.append(r)
         out["also"] = also
+        if D.world == 1:
+            out["branchopt"] = run_branchopt(pkg, synth)
 
     sys.stdout.flush()
     os.dup2(real_stdout, 1)

@@ -78,7 +78,12 @@ typedef struct iqhip_node_op {
 /* IQHIP_OP_NO_SCALE: never rescale this result.  A node of degree > 3 (the reference's scalar kernel multiplies ALL
  * children, applies U^-1 and tests for underflow once, phylotreesse.cpp:702-806) is submitted as a chain of binary
  * updates whose intermediate products travel over zero-length branches and carry this flag (iqhip_adapter.h). */
-enum { IQHIP_OP_NO_SCALE = 1 };
+/* IQHIP_OP_SCALAR_RULE: the node's own (last) update of such a chain applies the SCALAR kernel's scaling rule
+ * (phylotreesse.cpp:774-801): as the SIMD rule, plus -- before the ptn_invar test -- `lh_max == 0.0` ("very shitty data"):
+ * the pattern's vector becomes tip_partial_lh[STATE_UNKNOWN] in every category, scale_num += 4 and
+ * sum_scale += 4 * LOG_SCALING_THRESHOLD * ptn_freq.  Binary nodes go through the reference's SIMD kernel, which has no
+ * such branch (phylokernel.h:461-474), and carry neither flag. */
+enum { IQHIP_OP_NO_SCALE = 1, IQHIP_OP_SCALAR_RULE = 2 };
 
 /* One end of a branch for the lnL / theta calls. leaf >= 0 -> taxon id, else key. */
 typedef struct iqhip_branch_end {

@@ -214,7 +214,8 @@ inline void collectPlan(typename X::Tree *tree, typename X::Neighbor *dad_branch
         setChild<X>(op, false, kids[i]);
         plan.len_nb.push_back(kids[i]);
         op.dst_key = last ? dst : tempKey(dst, (int)i - 1);
-        op.flags = last ? 0u : (uint32_t)IQHIP_OP_NO_SCALE;
+        /* (a node of degree > 3 is the scalar kernel's, with its lh_max == 0 branch, phylotreesse.cpp:774-788) */
+        op.flags = last ? (kids.size() > 2 ? (uint32_t)IQHIP_OP_SCALAR_RULE : 0u) : (uint32_t)IQHIP_OP_NO_SCALE;
         plan.ops.push_back(op);
         plan.dst.push_back(last ? dad_branch : (Neighbor *)0);
         if (last)

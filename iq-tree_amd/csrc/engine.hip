@@ -969,7 +969,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         DevOp &d = e->h_ops[k];
         dummy_op(d);
         d.out_row = order[k];
-        d.no_scale = (o.flags & IQHIP_OP_NO_SCALE) ? 1 : 0;
+        d.no_scale = (o.flags & IQHIP_OP_NO_SCALE) ? 1 : ((o.flags & IQHIP_OP_SCALAR_RULE) ? 2 : 0);
         if (k > 0 && seg_of[k] != seg_of[k - 1]) prev_dst = -1;  // another workgroup: no register hand-over
         if (!(o.left_len >= 0.0) || !(o.right_len >= 0.0))
             return fail(IQHIP_ERR_INVALID, "negative or NaN branch length");
@@ -1868,13 +1868,13 @@ static int sweep_persistent4(iqhip_engine *e, const iqhip_sweep_step *steps, int
             d.rlen = o.right_len;
             d.llen_step = st.len_from ? st.len_from[2 * k] : -1;
             d.rlen_step = st.len_from ? st.len_from[2 * k + 1] : -1;
-            d.no_scale = (o.flags & IQHIP_OP_NO_SCALE) ? 1 : 0;
+            d.no_scale = (o.flags & IQHIP_OP_NO_SCALE) ? 1 : ((o.flags & IQHIP_OP_SCALAR_RULE) ? 2 : 0);
             d.row = (int32_t)row;
         }
         int rc = build_branch(e, st.a, st.b, 0.0, -1, &hs.br);
         if (rc) return rc;
     }
-    const int grid = sweep4_grid(e), nwaves = grid * 4;
+    const int grid = sweep4_grid(e), nwaves = grid * sweep4_waves(e);
     if ((int64_t)total_ops * nwaves > e->slab_cap) {
         HIPCHK(hipStreamSynchronize(e->stream));
         if (e->d_slab) hipFree(e->d_slab);

@@ -53,7 +53,8 @@ struct __attribute__((aligned(16))) DevOp {
     int32_t sr_slot;    //   the chunk (slot 0 is shared by all non-leaf children)
     int32_t push_hold;  // 1: copy this op's result into the HOLD registers (consumed by a CHILD_HOLD)
     int32_t out_row;    // row of the caller's op list this op answers (sum_scale[out_row]); plans may be reordered
-    int32_t no_scale;   // IQHIP_OP_NO_SCALE: intermediate product of a multifurcating node, never rescaled
+    int32_t no_scale;   // scaling rule: 0 SIMD kernel's; 1 never (IQHIP_OP_NO_SCALE: intermediate product of a multifurcating node);
+                        // 2 scalar kernel's (IQHIP_OP_SCALAR_RULE: + the lh_max == 0 branch, phylotreesse.cpp:774-788)
     // matrix-core kernels: transition tables of the LEAF children (K2, phylokernel.h:187-232,293-317), built per
     // submission by k_leaf_tables into an L2-resident buffer: tab[c][state][n] (n permuted to the accumulator
     // image, see kernels_mfma.hip leaf_tab_pos); dummy-valid for non-leaf children
@@ -96,7 +97,7 @@ struct __attribute__((aligned(16))) SweepOp {
     const uint8_t *ls, *rs;     // state rows of leaf children
     double llen, rlen;
     int32_t llen_step, rlen_step;  // >= 0: the child branch's length is the one that step of this sweep accepted
-    int32_t no_scale;
+    int32_t no_scale;           // scaling rule, as DevOp::no_scale
     int32_t row;                // row of the wave-partial slab / of the caller's concatenated sum_scale array
 };
 struct __attribute__((aligned(16))) SweepStep {
@@ -612,6 +613,7 @@ hipError_t launch_newton_state_update(iqhip_engine *e);
 
 // kernels_sweep.hip: a whole sweep of a 4-state engine in one launch; posts: [2][kNewtonPostEpochs][grid][2] all-ones
 int sweep4_grid(const iqhip_engine *e);
+int sweep4_waves(const iqhip_engine *e);   // waves per workgroup (8: one 512-thread workgroup for <= 8 tiles)
 hipError_t launch_sweep4(iqhip_engine *e, const SweepOp *d_ops, const SweepStep *d_steps, int nsteps, double x1, double x2,
                          double xacc, int max_steps, double diverge_x, double *posts, double *out);
 

@@ -145,6 +145,10 @@ __device__ __forceinline__ unsigned amax_hi(unsigned m, double v) {
     const unsigned h = (unsigned)__double2hiint(v) & 0x7fffffffu;
     return m > h ? m : h;
 }
+// exactly-zero test for the scalar kernel's `lh_max == 0.0` branch (IQHIP_OP_SCALAR_RULE ops only): any bit of |x|
+__device__ __forceinline__ unsigned nonzero_bits(double v) {
+    return ((unsigned)__double2hiint(v) & 0x7fffffffu) | (unsigned)__double2loint(v);
+}
 __device__ __forceinline__ unsigned group_max_u(unsigned v) {
     auto a = __builtin_amdgcn_permlane32_swap(v, v, false, false);
     v = a[0] > a[1] ? a[0] : a[1];
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
             const bool unkL = leafL && sL == A.state_unknown, unkR = leafR && sR == A.state_unknown;
             const double *vL = op.pf + tbase, *vR = op.ld + tbase;
             double *dst = op.dst + tbase;
-            unsigned lmax = 0;
+            unsigned lmax = 0, nz = 0;
             for (int c = 0; c < C; c++) {
                 // A operands of this category's class
                 const double *aU = sU, *aUi = sUi;
@@ -321,18 +325,24 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
                         if (16 * m + 4 * r < N) {  // whole 4-row group valid (N is a multiple of 4)
                             dst[(size_t)(c * N + row) * 16 + p] = O[m][r];
                             lmax = amax_hi(lmax, O[m][r]);
+                            if (op.no_scale == 2) nz |= nonzero_bits(O[m][r]);
                         }
                     }
             }
-            // column (pattern) max over the 4 lane groups
+            // column (pattern) max over the 4 lane groups (lmax orders the high words; a denormal below 2^-1042 still counts
+            // as non-zero for the scalar rule's exact test)
+            if (nz != 0 && lmax == 0) lmax = 1;
             lmax = group_max_u(lmax);
-            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThresholdHi) && (invar == 0.0) && !op.no_scale;
+            const int rule = op.no_scale;
+            const bool zero = rule == 2 && lmax == 0;   // the scalar kernel's `lh_max == 0.0`, phylotreesse.cpp:777-788
+            const bool do_scale = zero || (!(leafL && leafR) && (lmax < kScalingThresholdHi) && (invar == 0.0) && rule != 1);
             double my_scale = 0.0;
             if (__any(do_scale)) {
                 if (do_scale) {
-                    for (int e = g; e < B; e += 4) dst[(size_t)e * 16 + p] *= kScalingThresholdInv;
-                    sc += 1;
-                    if (g == 0 && ptn < A.nptn) my_scale = kLogScalingThreshold * freq;
+                    if (zero) for (int e = g; e < B; e += 4) dst[(size_t)e * 16 + p] = A.tipc[(size_t)A.state_unknown * B + e];
+                    else for (int e = g; e < B; e += 4) dst[(size_t)e * 16 + p] *= kScalingThresholdInv;
+                    sc += zero ? 4 : 1;
+                    if (g == 0 && ptn < A.nptn) my_scale = (zero ? 4.0 : 1.0) * (kLogScalingThreshold * freq);
                 }
             }
             if (g == 0) op.dst_sc[ptn] = (int16_t)sc;
@@ -596,7 +606,7 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
             // scalar fields of the op that are needed only in its tail: requested now
             int16_t *const dst_sc = op.dst_sc;
             const int out_row = op.out_row;
-            const bool no_scale = op.no_scale;
+            const int no_scale = op.no_scale;
             if (op.right_kind == CHILD_LOAD) {
                 // rare (PF, LOAD): read the right child now into the `prev` registers
                 const double *src = op.ld + tbase;
@@ -828,6 +838,18 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
                 }
                 TRACE_STAMP();   // contraction done, stores issued
             }
+            if (no_scale == 2 && lmax == 0) {   // scalar rule: exactly zero, or only below 2^-1042?
+                unsigned nz = 0;
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+#pragma unroll
+                    for (int m = 0; m < MTF; m++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) nz |= nonzero_bits(prev[c][m][r]);
+                    if (TAIL4) nz |= nonzero_bits(prevT[c]);
+                }
+                if (nz) lmax = 1;
+            }
             lmax = group_max_u(lmax);
             if constexpr (CS > 1) {  // maximum over the categories held by the other waves of this tile
                 __shared__ unsigned s_lmax[2][WG / 64][16];
@@ -839,31 +861,36 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
                 for (int q = 0; q < CS; q++) lmax = max(lmax, s_lmax[par][w0 + q][p]);
             }
 #if defined(IQHIP_MFMA_ABLATE_NOLOAD) || defined(IQHIP_MFMA_ABLATE_NOSTORE)
+            const bool zero = false;
             const bool do_scale = lmax == 0xffffffffu;  // (garbage inputs must not take the rescaling path in a timing build)
 #else
-            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThresholdHi) && (invar == 0.0) && !no_scale;
+            const bool zero = no_scale == 2 && lmax == 0;   // the scalar kernel's `lh_max == 0.0`, phylotreesse.cpp:777-788
+            const bool do_scale = zero || (!(leafL && leafR) && (lmax < kScalingThresholdHi) && (invar == 0.0) && no_scale != 1);
 #endif
             double my_scale = 0.0;
             if (__any(do_scale)) {
                 if (do_scale) {
 #pragma unroll
                     for (int c = 0; c < C; c++) {
+                        const double *tu = A.tipc + ((size_t)A.state_unknown * CT + coff + c) * N;   // unknown tip, this category
 #pragma unroll
                         for (int m = 0; m < MTF; m++)
 #pragma unroll
                             for (int r = 0; r < 4; r++) {
+                                if (zero) prev[c][m][r] = tu[16 * m + 4 * r + g]; else
                                 prev[c][m][r] *= kScalingThresholdInv;
                                 dst[(size_t)((coff + c) * N + 16 * m + 4 * r + g) * 16 + p] = prev[c][m][r];
                                 if (HOLDS && push) hold[((coff + c) * N + 16 * m + 4 * r) * 16] = prev[c][m][r];
                             }
                         if (TAIL4) {
+                            if (zero) prevT[c] = tu[16 * MTF + g]; else
                             prevT[c] *= kScalingThresholdInv;
                             dst[(size_t)((coff + c) * N + 16 * MTF + g) * 16 + p] = prevT[c];
                             if (HOLDS && push) hold[((coff + c) * N + 16 * MTF) * 16] = prevT[c];
                         }
                     }
-                    sc += 1;
-                    if (lead && g == 0 && ptn < A.nptn) my_scale = kLogScalingThreshold * freq;
+                    sc += zero ? 4 : 1;
+                    if (lead && g == 0 && ptn < A.nptn) my_scale = (zero ? 4.0 : 1.0) * (kLogScalingThreshold * freq);
                 }
             }
             prev_sc = sc;
@@ -966,7 +993,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_mix20(const TravMArgs A
             const int strideL = leafL ? N : N * 16, stepL = leafL ? 4 : 64;  // per component / per k-step
             const int strideR = leafR ? N : N * 16, stepR = leafR ? 4 : 64;
             double *dst = op.dst + tbase;
-            unsigned lmax = 0;
+            unsigned lmax = 0, nz = 0;
             double nl[KS], nr[KS];
 #pragma unroll
             for (int s = 0; s < KS; s++) { nl[s] = srcL[(size_t)c_lo * strideL + s * stepL]; nr[s] = srcR[(size_t)c_lo * strideR + s * stepR]; }
@@ -1024,7 +1051,9 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_mix20(const TravMArgs A
                 }
                 dst[(size_t)(c * N + 16 + g) * 16 + p] = o4;
                 lmax = amax_hi(lmax, o4);
+                if (op.no_scale == 2) nz |= nonzero_bits(O[0]) | nonzero_bits(O[1]) | nonzero_bits(O[2]) | nonzero_bits(O[3]) | nonzero_bits(o4);
             }
+            if (nz != 0 && lmax == 0) lmax = 1;   // (scalar rule: only an exact zero takes its lh_max == 0 branch)
             lmax = group_max_u(lmax);
             if constexpr (CS > 1) {
                 __shared__ unsigned s_lmax[2][WG / 64][16];
@@ -1035,13 +1064,16 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_mix20(const TravMArgs A
 #pragma unroll
                 for (int q = 0; q < CS; q++) lmax = max(lmax, s_lmax[par][w0 + q][p]);
             }
-            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThresholdHi) && (invar == 0.0) && !op.no_scale;
+            const int rule = op.no_scale;
+            const bool zero = rule == 2 && lmax == 0;   // the scalar kernel's `lh_max == 0.0`, phylotreesse.cpp:777-788
+            const bool do_scale = zero || (!(leafL && leafR) && (lmax < kScalingThresholdHi) && (invar == 0.0) && rule != 1);
             double my_scale = 0.0;
             if (__any(do_scale)) {
                 if (do_scale) {
-                    for (int e = c_lo * N + g; e < c_hi * N; e += 4) dst[(size_t)e * 16 + p] *= kScalingThresholdInv;
-                    sc += 1;
-                    if (lead && g == 0 && ptn < A.nptn) my_scale = kLogScalingThreshold * freq;
+                    if (zero) for (int e = c_lo * N + g; e < c_hi * N; e += 4) dst[(size_t)e * 16 + p] = A.tipc[(size_t)A.state_unknown * B + e];
+                    else for (int e = c_lo * N + g; e < c_hi * N; e += 4) dst[(size_t)e * 16 + p] *= kScalingThresholdInv;
+                    sc += zero ? 4 : 1;
+                    if (lead && g == 0 && ptn < A.nptn) my_scale = (zero ? 4.0 : 1.0) * (kLogScalingThreshold * freq);
                 }
             }
             if (lead && g == 0) op.dst_sc[ptn] = (int16_t)sc;
@@ -1218,21 +1250,26 @@ __device__ __forceinline__ void trav_rows64_body(const TravMArgs &A, const int v
                 lmax = amax_hi(lmax, O[r]);
             }
             prev = O;
+            const int rule = op.no_scale;
+            if (rule == 2 && lmax == 0 && (nonzero_bits(O[0]) | nonzero_bits(O[1]) | nonzero_bits(O[2]) | nonzero_bits(O[3])) != 0)
+                lmax = 1;   // (scalar rule: only an exact zero takes its lh_max == 0 branch)
             lmax = group_max_u(lmax);
             if (g == 0) s_lmax[par][wave][p] = lmax;
             __syncthreads();
             lmax = max(max(s_lmax[par][0][p], s_lmax[par][1][p]), max(s_lmax[par][2][p], s_lmax[par][3][p]));
-            const bool do_scale = !(leafL && leafR) && (lmax < kScalingThresholdHi) && (invar == 0.0) && !op.no_scale;
+            const bool zero = rule == 2 && lmax == 0;   // the scalar kernel's `lh_max == 0.0`, phylotreesse.cpp:777-788
+            const bool do_scale = zero || (!(leafL && leafR) && (lmax < kScalingThresholdHi) && (invar == 0.0) && rule != 1);
             double my_scale = 0.0;
             if (__any(do_scale)) {
                 if (do_scale) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
+                        if (zero) prev[r] = A.tipc[(size_t)A.state_unknown * 64 + 16 * wave + 4 * r + g]; else
                         prev[r] *= kScalingThresholdInv;
                         dst[(size_t)(16 * wave + 4 * r + g) * 16 + p] = prev[r];
                     }
-                    sc += 1;
-                    if (lead && g == 0 && ptn < A.nptn) my_scale = kLogScalingThreshold * freq;
+                    sc += zero ? 4 : 1;
+                    if (lead && g == 0 && ptn < A.nptn) my_scale = (zero ? 4.0 : 1.0) * (kLogScalingThreshold * freq);
                 }
             }
             prev_sc = sc;

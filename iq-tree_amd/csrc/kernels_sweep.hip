@@ -128,12 +128,20 @@ __device__ __forceinline__ void sweep_node_update(const CONST_AS SweepOp &op, co
         }
     }
     // scaling (SIMD rule, phylokernel.h:379-392, 461-474); TIP-TIP never scales
-    const bool do_scale = !(leafL && leafR) && (lh_max < kScalingThreshold) && (invar_p[ptn] == 0.0) && !op.no_scale;
+    // (the last update of a multifurcating node: the scalar kernel's rule, lh_max == 0 first, phylotreesse.cpp:774-788)
+    const int rule = op.no_scale;
+    const bool zero = rule == 2 && lh_max == 0.0;
+    const bool do_scale = zero || (!(leafL && leafR) && (lh_max < kScalingThreshold) && (invar_p[ptn] == 0.0) && rule != 1);
     if (do_scale) {
+        if (zero) {
 #pragma unroll
-        for (int e = 0; e < B; e++) out[e] *= kScalingThresholdInv;
-        sc += 1;
-        if (ptn < nptn) scale_acc += kLogScalingThreshold * freq_p[ptn];
+            for (int e = 0; e < B; e++) out[e] = s_tip[state_unknown * 4 + (e & 3)];
+        } else {
+#pragma unroll
+            for (int e = 0; e < B; e++) out[e] *= kScalingThresholdInv;
+        }
+        sc += zero ? 4 : 1;
+        if (ptn < nptn) scale_acc += (zero ? 4.0 : 1.0) * (kLogScalingThreshold * freq_p[ptn]);
     }
     double2 *d = reinterpret_cast<double2 *>(op.dst + tile * (64 * B)) + lane;
 #pragma unroll
@@ -141,27 +149,31 @@ __device__ __forceinline__ void sweep_node_update(const CONST_AS SweepOp &op, co
     op.dst_sc[ptn] = (int16_t)sc;
 }
 
-// REG: every wave owns at most one tile, whose theta then stays in registers for all evaluations of the step
-template <int C, bool REG>
-__global__ __launch_bounds__(256, 2) void k_sweep4(const SweepArgs A) {
+// REG: every wave owns at most one tile, whose theta then stays in registers for all evaluations of the step (and goes to
+// memory only in the last step: PhyloTree::theta_all after the sweep is that of the last branch).
+// WAVES = 8: an alignment of at most 8 tiles (512 patterns) is one workgroup of 512 threads -- no exchange between
+// workgroups at all -- whose wave sums are added in the order the two 4-wave workgroups of k_newton add them (same bits).
+template <int C, bool REG, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void k_sweep4(const SweepArgs A) {
     constexpr int B = 4 * C;
+    constexpr int NT = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *s_tip = smem;               // [32][4]
     double *s_ex = s_tip + 128;         // [2][B]
     double *s_tab = s_ex + 2 * B;       // [2][5B]
     double *s_v0 = s_tab + 10 * B, *s_v1 = s_v0 + B, *s_v2 = s_v1 + B;
-    double *s_red = s_v2 + B;           // [8]
-    double *s_bcast = s_red + 8;        // [2]
+    double *s_red = s_v2 + B;           // [2 * WAVES]
+    double *s_bcast = s_red + 16;       // [2]
     double *s_len = s_bcast + 2;        // [nsteps] accepted lengths of the steps so far
     __shared__ int s_fail;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int G = (int)gridDim.x, wg = (int)blockIdx.x;
-    const int gw = wg * 4 + wave;
+    const int gw = wg * WAVES + wave;
     const CONST_AS double *U = sw_const(A.evec);
     const CONST_AS double *uinv = sw_const(A.inv_evec);
     const CONST_AS SweepOp *ops = sw_const(A.ops);
     const CONST_AS SweepStep *steps = sw_const(A.steps);
-    for (int t = threadIdx.x; t < (A.state_unknown + 1) * 4; t += 256) s_tip[t] = A.tip[t];
+    for (int t = threadIdx.x; t < (A.state_unknown + 1) * 4; t += NT) s_tip[t] = A.tip[t];
     if (threadIdx.x == 0) s_fail = 0;
     const size_t per_parity = (size_t)kNewtonPostEpochs * G * 2;
 
@@ -175,14 +187,14 @@ __global__ __launch_bounds__(256, 2) void k_sweep4(const SweepArgs A) {
         for (int k = st.op_begin; k < st.op_begin + st.nops; k++) {
             const CONST_AS SweepOp &op = ops[k];
             __syncthreads();   // (s_len of the previous step is written; the previous op's regions are no longer read)
-            for (int t = threadIdx.x; t < 2 * B; t += 256) {
+            for (int t = threadIdx.x; t < 2 * B; t += NT) {
                 const int childi = t / B, e = t - childi * B;
                 const int from = childi ? op.rlen_step : op.llen_step;
                 const double len = from >= 0 ? s_len[from] : (childi ? op.rlen : op.llen);
                 s_ex[t] = exp(A.eval[e & 3] * (A.rates[e >> 2] * len));
             }
             __syncthreads();
-            for (int t = threadIdx.x; t < 2 * 5 * B; t += 256) {   // K2 tables of leaf children, the reference's association
+            for (int t = threadIdx.x; t < 2 * 5 * B; t += NT) {   // K2 tables of leaf children, the reference's association
                 const int childi = t / (5 * B), q = t - childi * (5 * B);
                 if ((childi ? op.rv : op.lv) != nullptr) continue;
                 const int row = q / B, e = q - row * B, c = e >> 2, x = e & 3;
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep4(const SweepArgs A) {
             }
             __syncthreads();
             double scale_acc = 0.0;
-            for (int64_t tile = gw; tile < A.ntiles; tile += (int64_t)G * 4)
+            for (int64_t tile = gw; tile < A.ntiles; tile += (int64_t)G * WAVES)
                 sweep_node_update<C>(op, s_ex, s_tab, s_tip, U, uinv, tile, lane, A.nptn, A.state_unknown, A.freq, A.invar, scale_acc);
             const double ws = __any(scale_acc != 0.0) ? sw_wsum(scale_acc) : 0.0;
             if (lane == 0) A.slab[(size_t)op.row * A.nwaves + gw] = ws;
@@ -210,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep4(const SweepArgs A) {
         // ---- theta = a .* b of the branch (phylokernel.h:535-573), kept in registers when the wave has one tile
         double th[REG ? B : 1];
         const bool have_tile = gw < A.ntiles;
-        for (int64_t tile = gw; tile < A.ntiles; tile += (int64_t)G * 4) {
+        for (int64_t tile = gw; tile < A.ntiles; tile += (int64_t)G * WAVES) {
             const int64_t ptn = tile * 64 + lane;
             const double2 *pb = reinterpret_cast<const double2 *>(st.br.b + tile * (64 * B)) + lane;
             const double2 *pa = st.br.a_kind == CHILD_LEAF ? nullptr : reinterpret_cast<const double2 *>(st.br.a + tile * (64 * B)) + lane;
@@ -223,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep4(const SweepArgs A) {
                 if (pa) av = pa[jj * 64];
                 else av = make_double2(s_tip[s * 4 + ((2 * jj) & 3)], s_tip[s * 4 + ((2 * jj + 1) & 3)]);
                 const double2 t = make_double2(av.x * bv.x, av.y * bv.y);
-                pt[jj * 64] = t;
+                if (!REG || j == A.nsteps - 1) pt[jj * 64] = t;
                 if (REG) { th[REG ? 2 * jj : 0] = t.x; th[REG ? 2 * jj + 1 : 0] = t.y; }
             }
         }
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep4(const SweepArgs A) {
         // exchanged between the workgroups in k_newton's posted form and fixed order
         auto eval_at = [&](double x, int mode, double &r0, double &r1) {
             __syncthreads();
-            for (int t = threadIdx.x; t < B; t += 256) {
+            for (int t = threadIdx.x; t < B; t += NT) {
                 const int c = t >> 2;
                 const double cof = A.evalc[t] * A.rates[c];
                 const double v = exp(cof * x) * A.props[c];
@@ -242,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep4(const SweepArgs A) {
             }
             __syncthreads();
             double adf = 0.0, addf = 0.0;
-            for (int64_t tile = gw; tile < A.ntiles; tile += (int64_t)G * 4) {
+            for (int64_t tile = gw; tile < A.ntiles; tile += (int64_t)G * WAVES) {
                 const int64_t ptn = tile * 64 + lane;
                 double lh = 0.0, d1 = 0.0, d2 = 0.0;
                 const double2 *p = reinterpret_cast<const double2 *>(A.theta + tile * (64 * B)) + lane;
@@ -278,6 +290,10 @@ __global__ __launch_bounds__(256, 2) void k_sweep4(const SweepArgs A) {
             __syncthreads();
             double p0 = (s_red[0] + s_red[2]) + (s_red[4] + s_red[6]);
             double p1 = (s_red[1] + s_red[3]) + (s_red[5] + s_red[7]);
+            if (WAVES == 8) {
+                p0 += (s_red[8] + s_red[10]) + (s_red[12] + s_red[14]);
+                p1 += (s_red[9] + s_red[11]) + (s_red[13] + s_red[15]);
+            }
             __syncthreads();
             if (G > 1) {
                 unsigned long long *slots = posts + (size_t)epoch * G * 2;
@@ -317,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep4(const SweepArgs A) {
                     // every workgroup has posted evaluation 0 of this step, so every workgroup is done with the previous
                     // step's slots (the other parity): back to "not posted" for the step after this one, and acknowledged
                     // before this workgroup posts anything else
-                    for (int t = threadIdx.x; t < kNewtonPostEpochs * 2; t += 256)
+                    for (int t = threadIdx.x; t < kNewtonPostEpochs * 2; t += NT)
                         __hip_atomic_store(&posts_other[((size_t)(t >> 1) * G + wg) * 2 + (t & 1)], ~0ull, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -366,17 +382,21 @@ __global__ __launch_bounds__(256, 2) void k_sweep4(const SweepArgs A) {
 }
 
 template <int C>
-static hipError_t launch_sweep_c(iqhip_engine *e, SweepArgs &A, int grid, bool reg) {
+static hipError_t launch_sweep_c(iqhip_engine *e, SweepArgs &A, int grid, bool reg, int waves) {
     constexpr int B = 4 * C;
-    const size_t lds = (size_t)(128 + 2 * B + 10 * B + 3 * B + 8 + 2 + A.nsteps) * sizeof(double);
-    if (reg) hipLaunchKernelGGL((k_sweep4<C, true>), dim3(grid), dim3(256), lds, e->stream, A);
-    else hipLaunchKernelGGL((k_sweep4<C, false>), dim3(grid), dim3(256), lds, e->stream, A);
+    const size_t lds = (size_t)(128 + 2 * B + 10 * B + 3 * B + 16 + 2 + A.nsteps) * sizeof(double);
+    if (waves == 8) hipLaunchKernelGGL((k_sweep4<C, true, 8>), dim3(1), dim3(512), lds, e->stream, A);
+    else if (reg) hipLaunchKernelGGL((k_sweep4<C, true, 4>), dim3(grid), dim3(256), lds, e->stream, A);
+    else hipLaunchKernelGGL((k_sweep4<C, false, 4>), dim3(grid), dim3(256), lds, e->stream, A);
     return hipGetLastError();
 }
 
 // grid: every workgroup must be resident for the exchange -- two per CU at most, as k_newton's posted form (whose tile ->
-// wave -> workgroup assignment this kernel shares, so that the derivative sums are the same bits)
+// wave -> workgroup assignment this kernel shares, so that the derivative sums are the same bits); up to 8 tiles: one
+// workgroup of 8 waves
+int sweep4_waves(const iqhip_engine *e) { return (e->ntiles > 4 && e->ntiles <= 8) ? 8 : 4; }
 int sweep4_grid(const iqhip_engine *e) {
+    if (sweep4_waves(e) == 8) return 1;
     const int64_t wgs = (e->ntiles + 3) / 4;
     const int64_t max_grid = 2 * (int64_t)e->num_cus;
     return (int)(wgs < 1 ? 1 : (wgs > max_grid ? max_grid : wgs));
@@ -399,8 +419,8 @@ hipError_t launch_sweep4(iqhip_engine *e, const SweepOp *d_ops, const SweepStep 
     A.invar = e->d_invar;
     A.theta = e->d_theta;
     A.slab = e->d_slab;
-    const int grid = sweep4_grid(e);
-    A.nwaves = grid * 4;
+    const int grid = sweep4_grid(e), waves = sweep4_waves(e);
+    A.nwaves = grid * waves;
     A.ntiles = e->ntiles;
     A.nptn = e->nptn;
     A.state_unknown = e->state_unknown;
@@ -411,16 +431,16 @@ hipError_t launch_sweep4(iqhip_engine *e, const SweepOp *d_ops, const SweepStep 
     A.max_steps = max_steps;
     A.posts = posts;
     A.out = out;
-    const bool reg = e->ntiles <= (int64_t)grid * 4;
+    const bool reg = e->ntiles <= (int64_t)grid * waves;
     switch (e->ncat) {
-        case 1: return launch_sweep_c<1>(e, A, grid, reg);
-        case 2: return launch_sweep_c<2>(e, A, grid, reg);
-        case 3: return launch_sweep_c<3>(e, A, grid, reg);
-        case 4: return launch_sweep_c<4>(e, A, grid, reg);
-        case 5: return launch_sweep_c<5>(e, A, grid, reg);
-        case 6: return launch_sweep_c<6>(e, A, grid, reg);
-        case 7: return launch_sweep_c<7>(e, A, grid, reg);
-        case 8: return launch_sweep_c<8>(e, A, grid, reg);
+        case 1: return launch_sweep_c<1>(e, A, grid, reg, waves);
+        case 2: return launch_sweep_c<2>(e, A, grid, reg, waves);
+        case 3: return launch_sweep_c<3>(e, A, grid, reg, waves);
+        case 4: return launch_sweep_c<4>(e, A, grid, reg, waves);
+        case 5: return launch_sweep_c<5>(e, A, grid, reg, waves);
+        case 6: return launch_sweep_c<6>(e, A, grid, reg, waves);
+        case 7: return launch_sweep_c<7>(e, A, grid, reg, waves);
+        case 8: return launch_sweep_c<8>(e, A, grid, reg, waves);
         default: return hipErrorInvalidValue;
     }
 }

@@ -398,15 +398,23 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
                                                           s_tip, U, uinv, sL, sR, A.state_unknown, nx_pf, dstp, coff, PF, HOLD, prev);
             if (SP == 2) lh_max = fmax(lh_max, __shfl_xor(lh_max, 32, 64));  // both category halves of the pattern
             // ---- scaling (SIMD rule, phylokernel.h:379-392,461-474); TIP-TIP never scales
-            const bool do_scale = !(leafL && leafR) && (lh_max < kScalingThreshold) && (invar == 0.0) && !op->no_scale;
+            // (the last update of a multifurcating node carries the scalar kernel's rule: lh_max == 0 first, phylotreesse.cpp:774-788)
+            const int rule = op->no_scale;
+            const bool zero = rule == 2 && lh_max == 0.0;
+            const bool do_scale = zero || (!(leafL && leafR) && (lh_max < kScalingThreshold) && (invar == 0.0) && rule != 1);
             double my_scale = 0.0;
             const unsigned long long any = __ballot(do_scale);
             if (__builtin_expect(any != 0, 0)) {  // rare, wave-uniform
                 if (do_scale) {
+                    if (zero) {   // "very shitty data": the unknown tip's vector in every category, four scaling events
 #pragma unroll
-                    for (int e = 0; e < BL; e++) prev[e] *= kScalingThresholdInv;
-                    sc += 1;
-                    my_scale = (lead && ptn < A.nptn) ? kLogScalingThreshold * freq : 0.0;
+                        for (int e = 0; e < BL; e++) prev[e] = s_tip[A.state_unknown * 4 + (e & 3)];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < BL; e++) prev[e] *= kScalingThresholdInv;
+                    }
+                    sc += zero ? 4 : 1;
+                    my_scale = (lead && ptn < A.nptn) ? (zero ? 4.0 : 1.0) * (kLogScalingThreshold * freq) : 0.0;
 #ifndef IQHIP_ABLATE_NOSTORE
                     store_vec4_off<CL>(op->dst, voff, prev);
 #endif

@@ -151,6 +151,6 @@ def test_multifurcating_node_becomes_a_chain_of_binary_updates(pkg, synth):
     assert (a["left_leaf"], a["right_leaf"]) == (0, 1) and (a["left_len"], a["right_len"]) == (0.1, 0.2)
     assert a["dst"][1] == -1 and b["dst"][1] == -1 and c["dst"][1] != -1      # only the last one answers a neighbour
     assert b["left_key"] == a["dst_key"] and b["left_len"] == 0.0 and b["right_leaf"] == 2 and b["flags"] == 1
-    assert c["left_key"] == b["dst_key"] and c["left_len"] == 0.0 and c["right_leaf"] == 5 and c["flags"] == 0
+    assert c["left_key"] == b["dst_key"] and c["left_len"] == 0.0 and c["right_leaf"] == 5 and c["flags"] == 2   # IQHIP_OP_SCALAR_RULE
     assert a["dst_key"] >> 63 == 1 and b["dst_key"] >> 63 == 1 and a["dst_key"] != b["dst_key"]
     assert c["dst_key"] >> 63 == 0
