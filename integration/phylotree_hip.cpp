@@ -54,6 +54,9 @@ bool PhyloTree::hipKernelUsable() {
         int limit = n == 20 ? 96 : n == 64 ? 16 : n == 4 ? 8 : 0;
         if (ncomp > limit) return false;
     }
+    // +ASC on a pattern-sharded engine (-hipdevs with several GPUs) is not implemented (iqhip_set_ascertainment refuses it):
+    // such runs keep the CPU kernels
+    if (!model_factory->unobserved_ptns.empty() && params->hip_devices.size() > 1) return false;
     // the reference's SIMD dispatch cases (phylotreesse.cpp:262-357): binary, DNA, protein, codon
     return (n == 2 || n == 4 || n == 20 || n == 64) && iqhip_device_count() > 0;
 }
@@ -192,9 +195,12 @@ double PhyloTree::computeLikelihoodFromBufferHIP() {
 // Newton-Raphson branch `optx = minimizeNewton(...)` replaced by ONE engine submission (pending
 // updates of both ends + theta + the whole minimizeNewton loop on the device; on a sharded engine the loop is an
 // enqueued chain with one in-stream all-reduce per step).  Hunk in optimizeOneBranch:
-//   if (optimize_by_newton && hip_engine && computePartialLikelihoodPointer == &PhyloTree::computePartialLikelihoodHIP
-//       && model_factory->unobserved_ptns.empty())
-//       optx = hipMinimizeNewton(current_len, maxNRStep); else ...        (+ASC keeps the host loop)
+//   if (optimize_by_newton && hip_engine && computePartialLikelihoodPointer == &PhyloTree::computePartialLikelihoodHIP)
+//       optx = hipMinimizeNewton(current_len, maxNRStep); else ...        (+ASC models included: phylokernel.h:655-725 runs
+//                                                                         inside the device solve)
+// The call leaves current_it / current_it_back at the length it returns -- the last evaluated point, as the reference's
+// computeFuncDerv does -- so the diverged-Newton test that follows in optimizeOneBranch (phylotree.cpp:2167-2176) evaluates
+// opt_lh = computeLikelihoodFromBuffer() at the right length, unchanged.
 double PhyloTree::hipMinimizeNewton(double current_len, int maxNRStep) {
     return iqhip_adapter::minimizeNewtonOnBranch<HipPolicy>(this, current_len, maxNRStep);
 }

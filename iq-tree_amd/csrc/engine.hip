@@ -1698,8 +1698,10 @@ extern "C" int iqhip_newton_branch(iqhip_engine *e, double xguess, double x1, do
     int rc = check_ready(e);
     if (rc) return rc;
     if (!e->theta_valid) return fail(IQHIP_ERR_INVALID, "iqhip_newton_branch: theta not computed");
-    if (e->n_unobs > 0) return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_newton_branch: +ASC uses iqhip_derv");
-    if (newton_use_chain(e)) return newton_chain(e, xguess, x1, x2, xacc, max_steps, optx, d2l, nsteps);
+    if (newton_use_chain(e)) {
+        if (e->n_unobs > 0) return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_newton_branch: the enqueued chain form has no +ASC correction; use iqhip_derv");
+        return newton_chain(e, xguess, x1, x2, xacc, max_steps, optx, d2l, nsteps);
+    }
     HIPCHK(launch_newton(e, xguess, x1, x2, xacc, max_steps, e->d_result));
     rc = read_result(e, 4);
     if (rc) return rc;
@@ -1708,6 +1710,7 @@ extern "C" int iqhip_newton_branch(iqhip_engine *e, double xguess, double x1, do
     if (status == 3) return fail(IQHIP_ERR_INVALID, "Maximum number of iterations exceeded in minimizeNewton");
     if (status == 4) {  // the grid barrier gave up (another kernel held the CUs): the chain needs no barrier
         (void)hipStreamSynchronize(e->stream);
+        if (e->n_unobs > 0) return fail(IQHIP_ERR_HIP, "Newton solve: the exchange between workgroups timed out (+ASC has no chain form)");
         return newton_chain(e, xguess, x1, x2, xacc, max_steps, optx, d2l, nsteps);
     }
     if (optx) *optx = e->h_result[0];
@@ -1724,10 +1727,10 @@ extern "C" int iqhip_optimize_branch(iqhip_engine *e, const iqhip_node_op *ops, 
     if (e && !e->shards.empty())
         return sharded::optimize_branch(e, ops, nops, true, a, b, xguess, x1, x2, xacc, max_steps, sum_scale, optx, d2l,
                                         nsteps);
-    if (e && e->n_unobs > 0) return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_optimize_branch: +ASC uses iqhip_derv");
     iqhip_branch_end none = {0, -1, 0};
     int rc = IQHIP_OK;
     if (e && newton_use_chain(e)) {
+        if (e->n_unobs > 0) return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_optimize_branch: the enqueued chain form has no +ASC correction; use iqhip_derv");
         // sharded rank: node updates (their sum_scale rows all-reduced), theta, then the enqueued Newton chain
         if (nops > 0) {
             rc = iqhip_update_partials(e, ops, nops, sum_scale);
@@ -1761,6 +1764,7 @@ extern "C" int iqhip_optimize_branch(iqhip_engine *e, const iqhip_node_op *ops, 
     if (status == 3) return fail(IQHIP_ERR_INVALID, "Maximum number of iterations exceeded in minimizeNewton");
     if (status == 4) {  // grid barrier gave up: theta was built by the first evaluation, finish with the chain
         (void)hipStreamSynchronize(e->stream);
+        if (e->n_unobs > 0) return fail(IQHIP_ERR_HIP, "Newton solve: the exchange between workgroups timed out (+ASC has no chain form)");
         return newton_chain(e, xguess, x1, x2, xacc, max_steps, optx, d2l, nsteps);
     }
     if (optx) *optx = r[0];

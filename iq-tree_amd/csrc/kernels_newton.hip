@@ -90,6 +90,9 @@ struct NewtonArgs {
     // branch-length sweeps (iqhip_optimize_sweep): the accepted length also goes to device memory, where the node
     // updates of the later steps of the same submission read it (DevOp::left_len_p / right_len_p)
     double *len_out;
+    // +ASC (phylokernel.h:655-725): patterns [nobs, nptn) are the unobserved constant patterns (nobs == nptn: no correction)
+    int64_t nobs;
+    double asc_nsites;
     // > 0: PhyloTree::optimizeOneBranch's "newton raphson diverged, reset" rule (phylotree.cpp:2167-2176) applied here:
     // a result above this length is kept only if the branch lnL there is not below the lnL at the starting length
     double diverge_x;
@@ -132,7 +135,7 @@ __device__ __forceinline__ void wg_partial(const NewtonArgs &A, const double *th
         bool mine;
         if (!A.mfma) {
             ptn = tile * 64 + lane;
-            mine = ptn < A.nptn;
+            mine = ptn < A.nobs;   // (the unobserved patterns of +ASC enter through asc_unobserved_sums only)
             const double2 *p = reinterpret_cast<const double2 *>(theta_c + tile * (64 * B)) + lane;
             const double2 *pb = nullptr, *pa = nullptr;
             const double *tp = nullptr;
@@ -158,7 +161,7 @@ __device__ __forceinline__ void wg_partial(const NewtonArgs &A, const double *th
         } else {
             const int p = lane & 15, g = lane >> 4;
             ptn = tile * 16 + p;
-            mine = (g == 0) && ptn < A.nptn;
+            mine = (g == 0) && ptn < A.nobs;
             const double *th = theta_c + (size_t)tile * 16 * B;
             const double *bv = nullptr, *av = nullptr, *tp = nullptr;
             if (BUILD) {
@@ -221,11 +224,82 @@ __device__ __forceinline__ void wg_partial(const NewtonArgs &A, const double *th
     __syncthreads();
 }
 
+// +ASC, computeLikelihoodDervEigenSIMD's tail (phylokernel.h:655-725): sums over the unobserved constant patterns of
+// {lh_ptn + ptn_invar, sum val1*theta, sum val2*theta} at the val arrays in LDS -- no rescaling, no weights.  There are
+// nstates such patterns, in the last tile(s); wave 0 of EVERY workgroup computes them for itself (theta of those
+// patterns from the resident theta_all, or on the fly from the branch ends while theta is being built by its owner), so
+// the exchange between the workgroups stays two doubles and every workgroup applies the same correction.
+template <bool BUILD>
+__device__ __forceinline__ void asc_unobserved_sums(const NewtonArgs &A, const double *theta_c, const DevBranch &br,
+                                                    const double *s_v0, const double *s_v1, const double *s_v2, double *s_asc) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const int B = A.n * A.ncat;
+        double u0 = 0.0, u1 = 0.0, u2 = 0.0;
+        const int T = A.mfma ? 16 : 64;
+        for (int64_t tile = A.nobs / T; tile * T < A.nptn; tile++) {
+            double lh = 0.0, d1 = 0.0, d2 = 0.0;
+            int64_t ptn;
+            bool mine;
+            if (!A.mfma) {
+                ptn = tile * 64 + lane;
+                mine = true;
+                const double2 *p = reinterpret_cast<const double2 *>(theta_c + tile * (64 * B)) + lane;
+                const double2 *pb = reinterpret_cast<const double2 *>(br.b + tile * (64 * B)) + lane;
+                const double2 *pa = nullptr;
+                const double *tp = nullptr;
+                if (BUILD) {
+                    if (br.a_kind == CHILD_LEAF) tp = A.tipc + (size_t)br.a_states[ptn] * B;
+                    else pa = reinterpret_cast<const double2 *>(br.a + tile * (64 * B)) + lane;
+                }
+                for (int j = 0; j < B / 2; j++) {
+                    double2 t;
+                    if (BUILD) {
+                        const double2 bv = pb[j * 64];
+                        const double2 av = tp ? make_double2(tp[2 * j], tp[2 * j + 1]) : pa[j * 64];
+                        t = make_double2(av.x * bv.x, av.y * bv.y);
+                    } else {
+                        t = p[j * 64];
+                    }
+                    lh = fma(s_v0[2 * j], t.x, lh); lh = fma(s_v0[2 * j + 1], t.y, lh);
+                    d1 = fma(s_v1[2 * j], t.x, d1); d1 = fma(s_v1[2 * j + 1], t.y, d1);
+                    d2 = fma(s_v2[2 * j], t.x, d2); d2 = fma(s_v2[2 * j + 1], t.y, d2);
+                }
+            } else {
+                const int p = lane & 15, g = lane >> 4;
+                ptn = tile * 16 + p;
+                mine = g == 0;
+                const double *th = theta_c + (size_t)tile * 16 * B;
+                const double *bv = br.b + (size_t)tile * 16 * B, *av = nullptr, *tp = nullptr;
+                if (BUILD) {
+                    if (br.a_kind == CHILD_LEAF) tp = A.tipc + (size_t)br.a_states[ptn] * B;
+                    else av = br.a + (size_t)tile * 16 * B;
+                }
+                for (int e = g; e < B; e += 4) {
+                    const double t = BUILD ? (tp ? tp[e] : av[(size_t)e * 16 + p]) * bv[(size_t)e * 16 + p] : th[(size_t)e * 16 + p];
+                    lh = fma(s_v0[e], t, lh);
+                    d1 = fma(s_v1[e], t, d1);
+                    d2 = fma(s_v2[e], t, d2);
+                }
+                lh = group_sum(lh);
+                d1 = group_sum(d1);
+                d2 = group_sum(d2);
+            }
+            const bool unobs = mine && ptn >= A.nobs && ptn < A.nptn;
+            const double w0 = wsum(unobs ? lh + A.invar[ptn] : 0.0), w1 = wsum(unobs ? d1 : 0.0), w2 = wsum(unobs ? d2 : 0.0);
+            u0 += w0; u1 += w1; u2 += w2;
+        }
+        if (lane == 0) { s_asc[0] = u0; s_asc[1] = u1; s_asc[2] = u2; }
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void k_newton(const NewtonArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int B = A.n * A.ncat;
     double *s_v0 = smem, *s_v1 = smem + B, *s_v2 = smem + 2 * B, *s_red = smem + 3 * B;  // s_red[8]
     __shared__ double s_bcast[2];
+    __shared__ double s_asc[3];
     __shared__ int s_fail;
     if (threadIdx.x == 0) s_fail = 0;
     // the arrival counters of consecutive launches alternate; this launch clears the next one's
@@ -274,6 +348,13 @@ __global__ __launch_bounds__(256) void k_newton(const NewtonArgs A) {
         }
         __syncthreads();
         double pdf, pddf;
+        const bool asc = A.nobs < A.nptn;
+        if (asc) {
+            // a launch that builds theta never reads another workgroup's theta tiles (they are plain stores of this very
+            // launch: not visible across workgroups without a release / acquire): from the branch ends in every evaluation
+            if (A.build) asc_unobserved_sums<true>(A, A.theta, A.br, s_v0, s_v1, s_v2, s_asc);
+            else asc_unobserved_sums<false>(A, A.theta, A.br, s_v0, s_v1, s_v2, s_asc);
+        }
         if (A.build && first) wg_partial<true>(A, A.theta, A.br, blockIdx.x, gridDim.x, s_v0, s_v1, s_v2, s_red, pdf, pddf);
         else wg_partial<false>(A, A.theta, A.br, blockIdx.x, gridDim.x, s_v0, s_v1, s_v2, s_red, pdf, pddf);
         first = false;
@@ -353,6 +434,12 @@ __global__ __launch_bounds__(256) void k_newton(const NewtonArgs A) {
             epoch++;
         }
         if (isnan(pdf) || isinf(pdf)) { pdf = 0.0; pddf = 0.0; }  // phylokernel.h:647-651
+        if (asc) {   // phylokernel.h:719-724
+            const double prob_const = 1.0 - s_asc[0];
+            const double df_frac = s_asc[1] / prob_const, ddf_frac = s_asc[2] / prob_const;
+            pdf += A.asc_nsites * df_frac;
+            pddf += A.asc_nsites * (ddf_frac + df_frac * df_frac);
+        }
         f = -pdf;
         df = -pddf;
     };
@@ -745,6 +832,10 @@ hipError_t launch_newton_batch(iqhip_engine *e, const void *d_tasks, int ntasks,
     A.mfma = e->mfma ? 1 : 0;
     A.xguess = A.x1 = A.x2 = A.xacc = 0.0;
     A.max_steps = 0;
+    A.len_out = nullptr;
+    A.diverge_x = 0.0;
+    A.nobs = e->nptn;   // (+ASC is refused for batches)
+    A.asc_nsites = 0.0;
     P.tasks = static_cast<const NewtonTask *>(d_tasks);
     P.theta_base = theta_base;
     P.theta_stride = theta_stride;
@@ -807,6 +898,8 @@ hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, d
                          const NewtonSweepStep *sweep) {
     NewtonArgs A;
     A.len_out = sweep ? sweep->len_out : nullptr;
+    A.nobs = e->nptn - e->n_unobs;
+    A.asc_nsites = e->asc_nsites;
     A.diverge_x = sweep ? sweep->diverge_x : 0.0;
     A.build = build_from ? 1 : 0;
     A.br = build_from ? *build_from : DevBranch{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.0};

@@ -720,7 +720,7 @@ void PhyloTree::optimizeOneBranch(PhyloNode *node1, PhyloNode *node2, bool clear
     theta_computed = false;
     double d2l;
     double optx;
-    if (device_newton && engine && !dry_run && !allreduce_hook && n_unobserved == 0) {
+    if (device_newton && engine && !dry_run && !allreduce_hook) {
         // one engine call: pending node updates of both ends + theta + the whole minimizeNewton solve (on a sharded
         // engine as an enqueued chain of steps with an in-stream all-reduce each); allreduce_hook is the legacy
         // caller-owned collective, which has to come back to the host between steps
@@ -765,7 +765,7 @@ double PhyloTree::optimizeAllBranches(int my_iterations, double tolerance, int m
     for (int i = 0; i < my_iterations; i++) {
         std::vector<double> lenvec;
         for (PhyloNeighbor *nb : all_neighbors) lenvec.push_back(nb->length);
-        if (device_sweep && device_newton && engine && !dry_run && !allreduce_hook && n_unobserved == 0) {
+        if (device_sweep && device_newton && engine && !dry_run && !allreduce_hook) {
             // the whole loop as one engine submission (iqhip_adapter::optimizeBranchSweep -> iqhip_optimize_sweep)
             theta_computed = false;
             int nevals = 0;

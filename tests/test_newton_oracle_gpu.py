@@ -80,3 +80,51 @@ def test_optimize_one_branch_is_the_reference_sequence(pkg, synth, oracle):
         assert abs(got - want) <= 1e-9 * max(1.0, want), (a, b, got, want, optx)
         ot.set_length(a, b, got)
     assert ndiv >= 3
+
+
+@pytest.mark.parametrize("n,ncat,seq_type,nsites", [(4, 4, 0, 500), (4, 4, 0, 25000), (20, 4, 1, 700), (64, 1, 2, 400)])
+def test_device_newton_with_ascertainment_correction(pkg, synth, oracle, n, ncat, seq_type, nsites):
+    """+ASC inside the one-launch solve (phylokernel.h:655-725: the derivative correction from the unobserved constant
+    patterns, computed by every workgroup for itself): same optimum and evaluation count as the oracle's minimizeNewton
+    over its +ASC derivative, on small (one workgroup) and larger (posted exchange) alignments; and the whole
+    optimizeAllBranches sweep -- device solve per branch, steps inside iqhip_optimize_sweep -- equals the host loop."""
+    import numpy as np
+    model = synth.gtr_model(alpha=0.9, ncat=ncat) if n == 4 else synth.random_reversible_model(n, 51, alpha=0.9 if ncat > 1 else None, ncat=ncat)
+    nwk = synth.random_tree_newick(9, 52, 0.02, 0.15)
+    st = synth.simulate_alignment(nwk, model, nsites, 53)
+    pat, freq = synth.compress_patterns(st)
+    const = np.all(pat == pat[0][None, :], axis=0)
+    pat, freq = np.ascontiguousarray(pat[:, ~const]), freq[~const].copy()
+    nun, ns = n, float(freq.sum())
+    pat = np.ascontiguousarray(np.concatenate([pat, np.tile(np.arange(n, dtype=np.uint8)[None, :], (9, 1))], axis=1))
+    freq = np.concatenate([freq, np.zeros(n)])
+    ot = oracle.OracleTree(nwk, n, seq_type, pat, freq, None, model, n_unobs=nun, nsites=ns)
+
+    def make():
+        t = pkg.PhyloTree(nwk)
+        t.set_alignment(n, seq_type, pat, freq)
+        t.set_ascertainment(nun, ns)
+        t.set_model(model)
+        t.attach_engine(0)
+        return t
+    t = make()
+    t.compute_likelihood()
+    edges = [(a, b) for a in range(t.num_nodes) for b, _ in t.neighbors(a) if a < b]
+    for (a, b) in edges[:4]:
+        t.reset_theta()
+        t.compute_likelihood_derv(a, b)
+        theta, _ = ot.theta(a, b)
+        for xg in (ot.length(a, b), 2.5):
+            ref_x, _, pts, status = ot.minimize_newton(a, b, 1e-6, xg, 100.0, 1e-6, 100, theta=theta)
+            optx, _, nsteps = device_newton(pkg, t, xg, 1e-6, 100.0, 1e-6, 100)
+            assert status == "ok" and nsteps == len(pts), (a, b, nsteps, pts)
+            assert abs(optx - ref_x) <= 1e-9 * max(1.0, abs(ref_x)), (a, b, optx, ref_x)
+    vals = []
+    for dev in (False, True):
+        t2 = make()
+        t2.set_device_newton(dev)
+        vals.append((t2.optimize_all_branches(iterations=2, tolerance=1e-6), t2.tree_string()))
+    assert abs(vals[0][0] - vals[1][0]) <= 1e-9 * abs(vals[0][0])
+    ot2 = oracle.OracleTree(vals[1][1], n, seq_type, pat, freq, None, model, n_unobs=nun, nsites=ns)
+    ref, _ = ot2.likelihood()
+    assert abs(vals[1][0] - ref) <= 1e-8 * abs(ref)

@@ -599,7 +599,7 @@ def test_ascertainment_bias_correction(pkg, synth, oracle, n, ncat, seq_type, pi
         w = t.compute_likelihood_from_buffer()
         o, _ = ot.lnl_from_theta(x, y)
         assert abs(w - o) <= LNL_RTOL * abs(o)
-    # branch optimisation falls back to the host Newton loop under +ASC and still improves the lnL
+    # branch optimisation (device Newton solve with the +ASC correction, tests/test_newton_oracle_gpu.py) improves the lnL
     assert t.optimize_all_branches(iterations=2, tolerance=1e-3) >= lnl - 1e-9 * abs(lnl)
 
 
