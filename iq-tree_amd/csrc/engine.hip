@@ -1976,6 +1976,7 @@ extern "C" int iqhip_optimize_sweep(iqhip_engine *e, const iqhip_sweep_step *ste
     }
     static const bool dbg = getenv("IQHIP_DEBUG_SWEEP") != nullptr;
     double t_trav = 0.0, t_newt = 0.0;
+    int n_uploaded = 0;
     timespec ts0;
     clock_gettime(CLOCK_MONOTONIC, &ts0);
     // result block in the (host-mapped) result vector: per step its sum_scale rows, then {optx, d2l, nsteps, status, diverged, -}
@@ -1999,7 +2000,7 @@ extern "C" int iqhip_optimize_sweep(iqhip_engine *e, const iqhip_sweep_step *ste
             if (dbg) clock_gettime(CLOCK_MONOTONIC, &ta);
             rc = submit_traverse(e, st.ops, st.nops, false, none, none, 0.0, /*skip_reduce=*/true, nullptr, lp);
             if (rc) return rc;
-            if (dbg) { clock_gettime(CLOCK_MONOTONIC, &tb); t_trav += (tb.tv_sec - ta.tv_sec) * 1e6 + (tb.tv_nsec - ta.tv_nsec) * 1e-3; }
+            if (dbg) { clock_gettime(CLOCK_MONOTONIC, &tb); t_trav += (tb.tv_sec - ta.tv_sec) * 1e6 + (tb.tv_nsec - ta.tv_nsec) * 1e-3; n_uploaded += e->plan_small ? 0 : 1; }
         }
         DevBranch br;
         rc = build_branch(e, st.a, st.b, 0.0, -1, &br);
@@ -2026,7 +2027,7 @@ extern "C" int iqhip_optimize_sweep(iqhip_engine *e, const iqhip_sweep_step *ste
     if (dbg) {
         timespec ts2;
         clock_gettime(CLOCK_MONOTONIC, &ts2);
-        fprintf(stderr, "[iqhip] sweep of %d steps: submit_traverse %.1f us, launch_newton %.1f us; enqueue %.1f us, wait %.1f us\n", nsteps, t_trav, t_newt,
+        fprintf(stderr, "[iqhip] sweep of %d steps (%d plans uploaded, the others in the kernel arguments): submit_traverse %.1f us, launch_newton %.1f us; enqueue %.1f us, wait %.1f us\n", nsteps, n_uploaded, t_trav, t_newt,
                 (ts1.tv_sec - ts0.tv_sec) * 1e6 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-3,
                 (ts2.tv_sec - ts1.tv_sec) * 1e6 + (ts2.tv_nsec - ts1.tv_nsec) * 1e-3);
     }
