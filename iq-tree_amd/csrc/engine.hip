@@ -242,6 +242,7 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
         if (p) hipFree(p);
     if (e->h_ops) hipHostFree(e->h_ops);
     if (e->h_sweep_desc) hipHostFree(e->h_sweep_desc);
+    if (e->h_plan_arena) hipHostFree(e->h_plan_arena);
     if (e->d_sweep_desc) hipFree(e->d_sweep_desc);
     if (e->d_sweep_posts) hipFree(e->d_sweep_posts);
     if (e->h_result) hipHostFree(e->h_result);
@@ -1246,6 +1247,17 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
     }
     if (e->uploaded_plan.size() == nbytes && memcmp(e->uploaded_plan.data(), e->h_ops, nbytes) == 0)
         return IQHIP_OK;
+    if (e->plan_arena_on && e->plan_arena_used + nbytes <= e->plan_arena_cap) {
+        // a sweep enqueues many plans before the device has run the first: each upload goes out of a slice of its own
+        // of a pinned arena, so that re-using h_ops for the next plan never has to wait for the device (that wait -- the
+        // staging event below -- made the host fall in step with the device eight times per 97-branch protein sweep)
+        char *slice = e->h_plan_arena + e->plan_arena_used;
+        memcpy(slice, e->h_ops, nbytes);
+        e->plan_arena_used += (nbytes + 255) / 256 * 256;
+        HIPCHK(hipMemcpyAsync(e->d_ops, slice, nbytes, hipMemcpyHostToDevice, e->stream));
+        e->uploaded_plan.assign((const char *)e->h_ops, (const char *)e->h_ops + nbytes);
+        return IQHIP_OK;
+    }
     HIPCHK(hipMemcpyAsync(e->d_ops, e->h_ops, nbytes, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipEventRecord(e->staging_free, e->stream));
     e->staging_busy = true;
@@ -1284,6 +1296,7 @@ static void timing_end(iqhip_engine *e) {
     e->tev_used++;
 }
 
+static double g_dbg_build_us = 0.0;   // IQHIP_DEBUG_SWEEP: host time spent in build_plan
 // enqueue: plan upload, K1, fused traversal (+ optional root lnL), fixed-order reduction
 static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, bool has_root,
                            iqhip_branch_end a, iqhip_branch_end b, double len, bool skip_reduce = false,
@@ -1292,8 +1305,12 @@ static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, 
     if (rc) return rc;
     if (nops < 0 || (nops > 0 && !ops)) return fail(IQHIP_ERR_INVALID, "bad ops array");
     int last_dst = -1;
+    static const bool dbg_t = getenv("IQHIP_DEBUG_SWEEP") != nullptr;
+    timespec q0, q1;
+    if (dbg_t) clock_gettime(CLOCK_MONOTONIC, &q0);
     rc = build_plan(e, ops, nops, &last_dst, explicit_segs, len_ptrs);
     if (rc) return rc;
+    if (dbg_t) { clock_gettime(CLOCK_MONOTONIC, &q1); g_dbg_build_us += (q1.tv_sec - q0.tv_sec) * 1e6 + (q1.tv_nsec - q0.tv_nsec) * 1e-3; }
     DevBranch br;
     if (has_root) {
         rc = build_branch(e, a, b, len, last_dst, &br);
@@ -1966,6 +1983,15 @@ extern "C" int iqhip_optimize_sweep(iqhip_engine *e, const iqhip_sweep_step *ste
     static const bool persistent = [] { const char *v = getenv("IQHIP_SWEEP_KERNEL"); return !v || atoi(v) != 0; }();
     if (persistent && !e->mfma && e->nclass == 1 && nsteps <= 4096 && max_steps + 5 <= kNewtonPostEpochs && total_ops > 0)
         return sweep_persistent4(e, steps, nsteps, total_ops, x1, x2, xacc, max_steps, diverge_frac, sum_scale, results);
+    if (!e->h_plan_arena) {
+        e->plan_arena_cap = 1 << 20;
+        if (hipHostMalloc((void **)&e->h_plan_arena, e->plan_arena_cap) != hipSuccess) { e->h_plan_arena = nullptr; e->plan_arena_cap = 0; }
+    }
+    struct ArenaScope {   // plan uploads of this sweep go through the arena; whatever happens, switched off on return
+        iqhip_engine *e;
+        explicit ArenaScope(iqhip_engine *e_) : e(e_) { e->plan_arena_on = e->h_plan_arena != nullptr; e->plan_arena_used = 0; }
+        ~ArenaScope() { e->plan_arena_on = false; }
+    } arena_scope(e);
     if (nsteps > e->sweep_len_cap) {
         HIPCHK(hipStreamSynchronize(e->stream));
         if (e->d_sweep_len) hipFree(e->d_sweep_len);
@@ -2027,9 +2053,10 @@ extern "C" int iqhip_optimize_sweep(iqhip_engine *e, const iqhip_sweep_step *ste
     if (dbg) {
         timespec ts2;
         clock_gettime(CLOCK_MONOTONIC, &ts2);
-        fprintf(stderr, "[iqhip] sweep of %d steps (%d plans uploaded, the others in the kernel arguments): submit_traverse %.1f us, launch_newton %.1f us; enqueue %.1f us, wait %.1f us\n", nsteps, n_uploaded, t_trav, t_newt,
+        fprintf(stderr, "[iqhip] sweep of %d steps (%d plans uploaded, the others in the kernel arguments): submit_traverse %.1f us (build_plan %.1f us since the last report), launch_newton %.1f us; enqueue %.1f us, wait %.1f us\n", nsteps, n_uploaded, t_trav, g_dbg_build_us, t_newt,
                 (ts1.tv_sec - ts0.tv_sec) * 1e6 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-3,
                 (ts2.tv_sec - ts1.tv_sec) * 1e6 + (ts2.tv_nsec - ts1.tv_nsec) * 1e-3);
+        g_dbg_build_us = 0.0;
     }
     size_t ss = 0;
     for (int j = 0; j < nsteps; j++) {

@@ -339,6 +339,9 @@ struct iqhip_engine {
     int sweep_len_cap = 0;
     // ... persistent form (4 states): descriptors of all steps (pinned staging + device copy) and the exchange slots
     char *h_sweep_desc = nullptr, *d_sweep_desc = nullptr;
+    char *h_plan_arena = nullptr;     // pinned slices for the plan uploads of a per-step sweep (build_plan)
+    size_t plan_arena_cap = 0, plan_arena_used = 0;
+    bool plan_arena_on = false;
     size_t sweep_desc_cap = 0;
     double *d_sweep_posts = nullptr;
     size_t sweep_posts_cap = 0;
