@@ -52,7 +52,7 @@ enum {
     IQHIP_OK = 0,
     IQHIP_ERR_NO_DEVICE = 1,   /* no HIP device / runtime failure at create */
     IQHIP_ERR_INVALID = 2,     /* bad argument (shape, key, leaf id, order of calls) */
-    IQHIP_ERR_UNSUPPORTED = 3, /* nstates not in {2,4,20,64} etc. */
+    IQHIP_ERR_UNSUPPORTED = 3, /* nstates outside 2..64, too many categories, ... */
     IQHIP_ERR_HIP = 4,         /* a HIP runtime call failed; see iqhip_last_error() */
     IQHIP_ERR_NOMEM = 5
 };
@@ -96,13 +96,15 @@ const char *iqhip_last_error(void);
 int iqhip_abi_version(void);
 int iqhip_device_count(void);
 
-/* nstates in {2, 4, 20, 64} (the reference's SIMD dispatch cases phylotreeavx.cpp:34-134 and, for binary data,
- * phylotreesse.cpp:262-276 <Vec2d, 2, 2>; other counts use the scalar kernel there and are IQHIP_ERR_UNSUPPORTED
- * here).  Binary data keeps the reference's shapes at this boundary (2x2 eigen-system, tip table of 3 rows,
- * states 0/1 and STATE_UNKNOWN = 2, vectors of 2*ncat doubles per pattern); no mixtures.
+/* nstates in 2 .. 64.  4, 20, 64 are the reference's SIMD dispatch cases (phylotreeavx.cpp:34-134), 2 its <Vec2d, 2, 2> case
+ * (phylotreesse.cpp:262-276); every other count (morphological / multi-state data) goes to the reference's scalar kernels
+ * (phylotreesse.cpp:281-309) and here runs on the next kernel size up (4 / 20 / 64) through an exact embedding, with the
+ * scalar kernel's scaling rule at every node.  All of them keep the reference's shapes at this boundary (n x n eigen-system,
+ * tip table of STATE_UNKNOWN + 1 rows, vectors of nstates*ncat doubles per pattern); embedded counts (everything but 4, 20,
+ * 64) have STATE_UNKNOWN = nstates and no mixtures.
  * nptn = aln->size() + unobserved patterns of this shard; ntaxa = leafNum.
- * ncat: 1..8 for 2 and 4 states; 1..16 for 64 states; 1..96 for 20 states (the (class, rate) components of a mixture
- * model count as categories, see iqhip_set_mixture_model). */
+ * ncat: 1..8 on the 4-state kernels; 1..16 on the 64-state kernels; 1..96 on the 20-state kernels (the (class, rate)
+ * components of a mixture model count as categories, see iqhip_set_mixture_model). */
 int iqhip_create(iqhip_engine **out, int device, int nstates, int ncat, int64_t nptn,
                  int ntaxa);
 void iqhip_destroy(iqhip_engine *e);

@@ -60,7 +60,8 @@ static void configure_engine(iqhip_engine *e, int device, int nstates, int nstat
     e->device = device;
     e->n = nstates;
     e->n_user = nstates_user;
-    e->embed2 = nstates_user == 2;
+    e->embed2 = nstates_user != nstates;   // the caller's state count is embedded into the next kernel size
+    e->scalar_rule_all = nstates_user != 2 && nstates_user != 4 && nstates_user != 20 && nstates_user != 64;
     e->ncat = ncat;
     e->ntaxa = ntaxa;
     e->nptn = nptn;
@@ -127,11 +128,10 @@ extern "C" int iqhip_create(iqhip_engine **out, int device, int nstates, int nca
     if (nptn <= 0 || ntaxa < 2 || ncat < 1)
         return fail(IQHIP_ERR_INVALID, "iqhip_create: bad nptn/ntaxa/ncat");
     const int nstates_user = nstates;
-    if (nstates == 2) nstates = 4;  // binary data runs on the 4-state kernels through an exact embedding (iqhip_internal.h)
-    if (nstates != 4 && nstates != 20 && nstates != 64)
-        return fail(IQHIP_ERR_UNSUPPORTED,
-                    "iqhip_create: nstates must be 2, 4, 20 or 64 (the reference's SIMD dispatch cases; "
-                    "other counts use its scalar kernel)");
+    // binary data, and every state count the reference hands to its scalar kernel (morphological / multi-state data,
+    // phylotreesse.cpp:281-309), run on the next kernel size up through an exact embedding (iqhip_internal.h: embed2)
+    if (nstates < 2 || nstates > 64) return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_create: nstates must be 2 .. 64");
+    nstates = nstates <= 4 ? 4 : nstates <= 20 ? 20 : 64;
     if (nstates == 4 && !(ncat >= 1 && ncat <= 8))
         return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_create: 4-state path supports ncat in {1..8}");
     if (nstates != 4 && ncat > (nstates == 20 ? 96 : 16))  // 20 states: (class, rate) components of mixtures
@@ -395,15 +395,17 @@ extern "C" int iqhip_set_alignment(iqhip_engine *e, const uint8_t *states, const
                     "iqhip_set_alignment: call iqhip_set_model first (needs state_unknown)");
     HIPCHK(use_device(e));
     const size_t P = (size_t)e->nptn_pad, N = (size_t)e->nptn;
-    // (binary data: padding patterns and missing characters are the ambiguity set {0, 1}, never the kernels' unknown)
-    std::vector<uint8_t> tmp((size_t)e->ntaxa * P, (uint8_t)(e->embed2 ? 6 : e->state_unknown));
+    // (embedded data: padding patterns and missing characters are the ambiguity code whose tip row is the caller's
+    // unknown row -- internal state n -- never the kernels' own unknown state, whose probability-space vector of exactly
+    // 1.0 in every component would leak into the padding components)
+    std::vector<uint8_t> tmp((size_t)e->ntaxa * P, (uint8_t)(e->embed2 ? e->n : e->state_unknown));
     for (int t = 0; t < e->ntaxa; t++) {
         const uint8_t *src = states + (size_t)t * N;
         if (e->embed2) {
             uint8_t *dst = tmp.data() + (size_t)t * P;
             for (size_t p = 0; p < N; p++) {
-                if (src[p] > 2) return fail(IQHIP_ERR_INVALID, "iqhip_set_alignment: state > STATE_UNKNOWN");
-                dst[p] = src[p] == 2 ? 6 : src[p];
+                if (src[p] > e->n_user) return fail(IQHIP_ERR_INVALID, "iqhip_set_alignment: state > STATE_UNKNOWN");
+                dst[p] = src[p] == e->n_user ? (uint8_t)e->n : src[p];
             }
             continue;
         }
@@ -600,23 +602,24 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
     return IQHIP_OK;
 }
 
-// binary data: pad the caller's 2-state system to the 4-state one the kernels run (see iqhip_engine::embed2)
+// embedded data: pad the caller's m-state system (m = n_user) to the n-state one the kernels run (see iqhip_engine::embed2):
+// eigenvalues (l_0 .. l_m-1, 0 ...), U = diag(U_m, I), U^-1 = diag(U_m^-1, I); tip rows of the m states padded with zeros;
+// internal state n = "missing" with the caller's unknown row, internal STATE_UNKNOWN = n + 1 (never present in the data)
 static int set_model_binary(iqhip_engine *e, const double *eval, const double *evec, const double *inv_evec,
                             const double *rates, const double *props, int state_unknown, const double *tip) {
     if (!eval || !evec || !inv_evec || !rates || !props || !tip) return fail(IQHIP_ERR_INVALID, "null argument");
-    if (state_unknown != 2) return fail(IQHIP_ERR_INVALID, "iqhip_set_model: binary data has STATE_UNKNOWN = 2");
-    double ev4[4] = {eval[0], eval[1], 0.0, 0.0};
-    double U4[16] = {0}, Ui4[16] = {0};
-    for (int x = 0; x < 2; x++)
-        for (int i = 0; i < 2; i++) { U4[x * 4 + i] = evec[x * 2 + i]; Ui4[x * 4 + i] = inv_evec[x * 2 + i]; }
-    U4[10] = U4[15] = Ui4[10] = Ui4[15] = 1.0;
-    std::vector<double> tip4((size_t)19 * 4, 0.0);  // DNA-style table: rows 0, 1 = the two states, row 6 = {0, 1} = missing
-    for (int i = 0; i < 2; i++) {
-        tip4[0 * 4 + i] = tip[0 * 2 + i];
-        tip4[1 * 4 + i] = tip[1 * 2 + i];
-        tip4[6 * 4 + i] = tip[2 * 2 + i];
-    }
-    return set_model_common(e, 1, nullptr, ev4, U4, Ui4, rates, props, 18, tip4.data());
+    const int m = e->n_user, n = e->n;
+    if (state_unknown != m)
+        return fail(IQHIP_ERR_INVALID, "iqhip_set_model: data of this state count has STATE_UNKNOWN = nstates (no ambiguity codes)");
+    std::vector<double> ev((size_t)n, 0.0), U((size_t)n * n, 0.0), Ui((size_t)n * n, 0.0), tp((size_t)(n + 2) * n, 0.0);
+    for (int i = 0; i < m; i++) ev[i] = eval[i];
+    for (int x = 0; x < m; x++)
+        for (int i = 0; i < m; i++) { U[(size_t)x * n + i] = evec[x * m + i]; Ui[(size_t)x * n + i] = inv_evec[x * m + i]; }
+    for (int x = m; x < n; x++) U[(size_t)x * n + x] = Ui[(size_t)x * n + x] = 1.0;
+    for (int st = 0; st < m; st++)
+        for (int i = 0; i < m; i++) tp[(size_t)st * n + i] = tip[st * m + i];
+    for (int i = 0; i < m; i++) tp[(size_t)n * n + i] = tip[m * m + i];   // row n: the caller's unknown row
+    return set_model_common(e, 1, nullptr, ev.data(), U.data(), Ui.data(), rates, props, n + 1, tp.data());
 }
 
 extern "C" int iqhip_set_model(iqhip_engine *e, const double *eval, const double *evec,
@@ -630,8 +633,8 @@ extern "C" int iqhip_set_model(iqhip_engine *e, const double *eval, const double
 extern "C" int iqhip_set_mixture_model(iqhip_engine *e, int nclass, const int32_t *cat_class, const double *eval,
                                        const double *evec, const double *inv_evec, const double *rates,
                                        const double *props, int state_unknown, const double *tip_partial_lh) {
-    if (e && (e->embed2 || e->n_user == 2) && nclass > 1)
-        return fail(IQHIP_ERR_UNSUPPORTED, "mixture models of binary data are not implemented");
+    if (e && (e->embed2 || (e->n_user != 4 && e->n_user != 20 && e->n_user != 64)) && nclass > 1)
+        return fail(IQHIP_ERR_UNSUPPORTED, "mixture models of embedded data (state counts other than 4, 20, 64) are not implemented");
     if (e && e->embed2 && e->shards.empty())
         return set_model_binary(e, eval, evec, inv_evec, rates, props, state_unknown, tip_partial_lh);
     return set_model_common(e, nclass, cat_class, eval, evec, inv_evec, rates, props, state_unknown, tip_partial_lh);
@@ -970,7 +973,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         DevOp &d = e->h_ops[k];
         dummy_op(d);
         d.out_row = order[k];
-        d.no_scale = (o.flags & IQHIP_OP_NO_SCALE) ? 1 : ((o.flags & IQHIP_OP_SCALAR_RULE) ? 2 : 0);
+        d.no_scale = (o.flags & IQHIP_OP_NO_SCALE) ? 1 : (((o.flags & IQHIP_OP_SCALAR_RULE) || e->scalar_rule_all) ? 2 : 0);
         if (k > 0 && seg_of[k] != seg_of[k - 1]) prev_dst = -1;  // another workgroup: no register hand-over
         if (!(o.left_len >= 0.0) || !(o.right_len >= 0.0))
             return fail(IQHIP_ERR_INVALID, "negative or NaN branch length");
@@ -1889,7 +1892,7 @@ static int sweep_persistent4(iqhip_engine *e, const iqhip_sweep_step *steps, int
             d.rlen = o.right_len;
             d.llen_step = st.len_from ? st.len_from[2 * k] : -1;
             d.rlen_step = st.len_from ? st.len_from[2 * k + 1] : -1;
-            d.no_scale = (o.flags & IQHIP_OP_NO_SCALE) ? 1 : ((o.flags & IQHIP_OP_SCALAR_RULE) ? 2 : 0);
+            d.no_scale = (o.flags & IQHIP_OP_NO_SCALE) ? 1 : (((o.flags & IQHIP_OP_SCALAR_RULE) || e->scalar_rule_all) ? 2 : 0);
             d.row = (int32_t)row;
         }
         int rc = build_branch(e, st.a, st.b, 0.0, -1, &hs.br);
@@ -2352,10 +2355,11 @@ static int fetch_vec(iqhip_engine *e, const double *dptr, double *out) {
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(tmp.data(), dptr, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
     const int B = e->block;
-    if (e->embed2) {  // the caller's block is 2 doubles per category: components 0, 1 of the embedded vector
+    if (e->embed2) {  // the caller's block is n_user doubles per category: the first components of the embedded vector
+        const int m = e->n_user, n = e->n;
         for (int64_t p = 0; p < e->nptn; p++)
             for (int c = 0; c < e->ncat; c++)
-                for (int i = 0; i < 2; i++) out[((size_t)p * e->ncat + c) * 2 + i] = tmp[dev_index(e, p, c * 4 + i)];
+                for (int i = 0; i < m; i++) out[((size_t)p * e->ncat + c) * m + i] = tmp[dev_index(e, p, c * n + i)];
         return IQHIP_OK;
     }
     for (int64_t p = 0; p < e->nptn; p++)
@@ -2506,9 +2510,10 @@ extern "C" int iqhip_upload_partial(iqhip_engine *e, uint64_t key, const double 
     const int B = e->block;
     std::vector<double> tmp((size_t)e->nptn_pad * B, 0.0);
     if (e->embed2) {
+        const int m = e->n_user, n = e->n;
         for (int64_t p = 0; p < e->nptn; p++)
             for (int c = 0; c < e->ncat; c++)
-                for (int i = 0; i < 2; i++) tmp[dev_index(e, p, c * 4 + i)] = partial_lh[((size_t)p * e->ncat + c) * 2 + i];
+                for (int i = 0; i < m; i++) tmp[dev_index(e, p, c * n + i)] = partial_lh[((size_t)p * e->ncat + c) * m + i];
     } else
     for (int64_t p = 0; p < e->nptn; p++)
         for (int k = 0; k < B; k++) tmp[dev_index(e, p, k)] = partial_lh[(size_t)p * B + k];

@@ -197,6 +197,12 @@ struct iqhip_engine {
     // C", whose tip vector is the caller's unknown row) instead of the kernels' "unknown = exactly 1.0 in every
     // component" rule, which would leak into the padding.  n stays 4 internally; the ABI speaks n_user = 2.
     bool embed2 = false;
+    // The same embedding carries every state count the reference hands to its scalar kernel (3, 5 .. 19, 21 .. 63: morphological
+    // / multi-state data, phylotreesse.cpp:281-309) on the next kernel size up (4 / 20 / 64): U = diag(U_m, I), zero
+    // eigenvalues and zero tip components in the padding; internal state n = "missing" (the caller's unknown row), the
+    // kernels' own unknown state n + 1 never occurs.  scalar_rule_all: such engines apply the scalar kernel's scaling rule
+    // (IQHIP_OP_SCALAR_RULE, incl. its lh_max == 0 branch) at every node, as the reference does for them.
+    bool scalar_rule_all = false;
     int n_user = 0;
     int64_t nptn = 0;      // caller-visible patterns
     int64_t nptn_pad = 0;  // padded to the tile size

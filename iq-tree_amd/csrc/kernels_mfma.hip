@@ -334,7 +334,7 @@ __global__ __launch_bounds__(WG) void k_traverse_mfma(const TravMArgs A) {
             if (nz != 0 && lmax == 0) lmax = 1;
             lmax = group_max_u(lmax);
             const int rule = op.no_scale;
-            const bool zero = rule == 2 && lmax == 0;   // the scalar kernel's `lh_max == 0.0`, phylotreesse.cpp:777-788
+            const bool zero = rule == 2 && !(leafL && leafR) && lmax == 0;   // the scalar kernel's `lh_max == 0.0`, phylotreesse.cpp:777-788
             const bool do_scale = zero || (!(leafL && leafR) && (lmax < kScalingThresholdHi) && (invar == 0.0) && rule != 1);
             double my_scale = 0.0;
             if (__any(do_scale)) {
@@ -864,7 +864,7 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
             const bool zero = false;
             const bool do_scale = lmax == 0xffffffffu;  // (garbage inputs must not take the rescaling path in a timing build)
 #else
-            const bool zero = no_scale == 2 && lmax == 0;   // the scalar kernel's `lh_max == 0.0`, phylotreesse.cpp:777-788
+            const bool zero = no_scale == 2 && !(leafL && leafR) && lmax == 0;   // the scalar kernel's `lh_max == 0.0`, phylotreesse.cpp:777-788
             const bool do_scale = zero || (!(leafL && leafR) && (lmax < kScalingThresholdHi) && (invar == 0.0) && no_scale != 1);
 #endif
             double my_scale = 0.0;
@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse_mfma_mix20(const TravMArgs A
                 for (int q = 0; q < CS; q++) lmax = max(lmax, s_lmax[par][w0 + q][p]);
             }
             const int rule = op.no_scale;
-            const bool zero = rule == 2 && lmax == 0;   // the scalar kernel's `lh_max == 0.0`, phylotreesse.cpp:777-788
+            const bool zero = rule == 2 && !(leafL && leafR) && lmax == 0;   // the scalar kernel's `lh_max == 0.0`, phylotreesse.cpp:777-788
             const bool do_scale = zero || (!(leafL && leafR) && (lmax < kScalingThresholdHi) && (invar == 0.0) && rule != 1);
             double my_scale = 0.0;
             if (__any(do_scale)) {
@@ -1257,7 +1257,7 @@ __device__ __forceinline__ void trav_rows64_body(const TravMArgs &A, const int v
             if (g == 0) s_lmax[par][wave][p] = lmax;
             __syncthreads();
             lmax = max(max(s_lmax[par][0][p], s_lmax[par][1][p]), max(s_lmax[par][2][p], s_lmax[par][3][p]));
-            const bool zero = rule == 2 && lmax == 0;   // the scalar kernel's `lh_max == 0.0`, phylotreesse.cpp:777-788
+            const bool zero = rule == 2 && !(leafL && leafR) && lmax == 0;   // the scalar kernel's `lh_max == 0.0`, phylotreesse.cpp:777-788
             const bool do_scale = zero || (!(leafL && leafR) && (lmax < kScalingThresholdHi) && (invar == 0.0) && rule != 1);
             double my_scale = 0.0;
             if (__any(do_scale)) {

@@ -130,7 +130,7 @@ __device__ __forceinline__ void sweep_node_update(const CONST_AS SweepOp &op, co
     // scaling (SIMD rule, phylokernel.h:379-392, 461-474); TIP-TIP never scales
     // (the last update of a multifurcating node: the scalar kernel's rule, lh_max == 0 first, phylotreesse.cpp:774-788)
     const int rule = op.no_scale;
-    const bool zero = rule == 2 && lh_max == 0.0;
+    const bool zero = rule == 2 && !(leafL && leafR) && lh_max == 0.0;   // (TIP-TIP never scales)
     const bool do_scale = zero || (!(leafL && leafR) && (lh_max < kScalingThreshold) && (invar_p[ptn] == 0.0) && rule != 1);
     if (do_scale) {
         if (zero) {

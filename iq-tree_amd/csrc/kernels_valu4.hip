@@ -400,7 +400,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
             // ---- scaling (SIMD rule, phylokernel.h:379-392,461-474); TIP-TIP never scales
             // (the last update of a multifurcating node carries the scalar kernel's rule: lh_max == 0 first, phylotreesse.cpp:774-788)
             const int rule = op->no_scale;
-            const bool zero = rule == 2 && lh_max == 0.0;
+            const bool zero = rule == 2 && !(leafL && leafR) && lh_max == 0.0;   // (TIP-TIP never scales, scalar kernel :807-843)
             const bool do_scale = zero || (!(leafL && leafR) && (lh_max < kScalingThreshold) && (invar == 0.0) && rule != 1);
             double my_scale = 0.0;
             const unsigned long long any = __ballot(do_scale);

@@ -293,8 +293,10 @@ static void branch_val(int n, int ncat, const double *eval, const double *rates,
 /* lane-strided running sum over patterns then (l0+l1)+(l2+l3):
  * phylokernel.h:836,954 + vectorclass/vectorf256.h:1652-1657 */
 /* vector width of the reference instantiation: Vec4d (AVX) for 4 / 20 / 64 states, Vec2d (SSE) for binary data */
-#define VCW(n) ((n) == 2 ? 2 : 4)
-static inline double hsum_l(const double *l, int vc) { return vc == 2 ? l[0] + l[1] : (l[0] + l[1]) + (l[2] + l[3]); }
+/* ... and plain running sums (width 1) for every other state count: those go to the reference's SCALAR kernels
+ * (phylotreesse.cpp:281-309 -> :1013-1339: `lh_ptn += val * partial_lh_node * partial_lh_dad`, `tree_lh += lh_ptn * freq`) */
+#define VCW(n) ((n) == 2 ? 2 : (((n) == 4 || (n) == 20 || (n) == 64) ? 4 : 1))
+static inline double hsum_l(const double *l, int vc) { return vc == 1 ? l[0] : (vc == 2 ? l[0] + l[1] : (l[0] + l[1]) + (l[2] + l[3])); }
 typedef struct { double l[4]; int vc; } lane4;
 static inline void lane4_acc(lane4 *s, size_t ptn, double v, double f) {
     const size_t k = ptn % (size_t)s->vc;

@@ -269,7 +269,9 @@ class OracleTree:
         self._ctx()
         assert not self.is_leaf(to)
         kids = [(nb, ln) for nb, ln in self.adj[to] if nb != frm]
-        if len(kids) > 2:  # multifurcating node: the reference's scalar kernel (phylotreesse.cpp:702-806)
+        # multifurcating node, or a state count outside the SIMD dispatch cases: the reference's scalar kernel
+        # (phylotreesse.cpp:702-806; :281-309 sends every state count but 2 / 4 / 20 / 64 there)
+        if len(kids) > 2 or self.n not in (2, 4, 20, 64):
             res = self._partial_multi(to, kids)
             self.cache[key] = res
             return res

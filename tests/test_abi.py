@@ -60,8 +60,9 @@ def test_no_cpu_fallback_without_gpu(pkg):
 def test_unsupported_shapes_are_rejected(pkg):
     lib = pkg.libiqhip()
     e = C.c_void_p()
-    assert lib.iqhip_create(C.byref(e), 0, 5, 4, 100, 5) == 3   # nstates 5: UNSUPPORTED (reference: scalar kernel)
-    assert lib.iqhip_create(C.byref(e), 0, 3, 4, 100, 5) == 3   # (2 = binary data is supported: tests/test_binary_gpu.py)
+    assert lib.iqhip_create(C.byref(e), 0, 1, 4, 100, 5) == 3   # nstates outside 2 .. 64: UNSUPPORTED
+    assert lib.iqhip_create(C.byref(e), 0, 65, 4, 100, 5) == 3  # (every count in between is embedded: tests/test_other_states_gpu.py)
+    assert lib.iqhip_create(C.byref(e), 0, 3, 9, 100, 5) == 3   # 3 states run on the 4-state kernels: at most 8 categories
     assert lib.iqhip_create(C.byref(e), 0, 4, 4, 0, 5) == 2     # nptn 0: INVALID
     # a 4-state vector of 4 GiB or more would wrap the kernels' 32-bit per-lane offsets: refused, not corrupted
     assert lib.iqhip_create(C.byref(e), 0, 4, 4, (1 << 32) // (16 * 8), 5) == 3

@@ -189,3 +189,28 @@ def test_oracle_multifurcating_nodes_match_textbook(synth, oracle, n, ncat, seq_
         for y, _ in tree.adj[x]:
             if x < y:
                 assert abs(tree.branch_lnl(x, y)[0] - ref) <= 1e-9 * abs(ref)
+
+
+@pytest.mark.parametrize("n,ncat", [(3, 4), (5, 1), (7, 3), (13, 4), (21, 1), (33, 2), (61, 1)])
+def test_scalar_kernel_state_counts_against_textbook(synth, oracle, n, ncat):
+    """state counts outside 2 / 4 / 20 / 64 take the reference's scalar kernels (phylotreesse.cpp:281-309): the oracle
+    restates those with plain running sums (VCW = 1) and the scalar node update; checked here against the
+    probability-space recursion, derivatives against finite differences"""
+    import textbook
+    model = synth.random_reversible_model(n, 11, alpha=0.9 if ncat > 1 else None, ncat=ncat)
+    nwk = synth.random_tree_newick(8, 5)
+    st = synth.simulate_alignment(nwk, model, 300, 6, 0.03, n)
+    pat, freq = synth.compress_patterns(st)
+    ot = oracle.OracleTree(nwk, n, 3, pat, freq, None, model)
+    lnl, (a, b) = ot.likelihood()
+    sl = textbook.site_log_likelihoods(ot.adj, pat, model, 3, n)
+    assert abs(lnl - (sl * freq).sum()) <= 1e-12 * abs(lnl)
+    df, _ = ot.derv(a, b)
+    h, L = 1e-5, ot.length(a, b)
+    ot.set_length(a, b, L + h)
+    lp, _ = ot.likelihood()
+    ot.set_length(a, b, L - h)
+    lm, _ = ot.likelihood()
+    assert abs(df - (lp - lm) / (2 * h)) <= 1e-5 * max(1.0, abs(df))
+    ot.set_length(a, b, L)
+    assert ot.lnl_from_theta(a, b)[0] == pytest.approx(lnl, rel=1e-13)
