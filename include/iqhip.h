@@ -155,7 +155,11 @@ int iqhip_set_ptn_invar(iqhip_engine *e, const double *ptn_invar); /* +I changed
  * iqhip_set_alignment are the unobserved constant patterns (ModelFactory::unobserved_ptns,
  * phylokernel.h:87; frequency 0, ptn_invar = p_invar*pi) and nsites = aln->getNSite().  The lnL and
  * derivative calls then apply phylokernel.h:868-909,968-1016 (branch), :655-725 (derivatives) and
- * :1124-1187 (from buffer).  0 switches it off.  Not available with the *_async / Newton calls. */
+ * :1124-1187 (from buffer), also inside iqhip_newton_branch / iqhip_optimize_sweep.  0 switches it off.  Not available
+ * with the *_async calls and the batched NNI evaluator.  Sharded engines (iqhip_create_sharded): the unobserved patterns
+ * must fit the last shard; prob_const / df_const / ddf_const are reduced with the result.  Comm engines
+ * (iqhip_comm_init_rank): the rank holding the unobserved patterns (the last one) passes their number, every other
+ * rank passes (0, nsites). */
 int iqhip_set_ascertainment(iqhip_engine *e, int64_t n_unobserved, double nsites);
 
 /* Model side inputs (model/modelsubst.h:248-258, model/rateheterogeneity.h:95-141,

@@ -54,9 +54,10 @@ bool PhyloTree::hipKernelUsable() {
         int limit = n == 20 ? 96 : n == 64 ? 16 : n == 4 ? 8 : 0;
         if (ncomp > limit) return false;
     }
-    // +ASC on a pattern-sharded engine (-hipdevs with several GPUs) is not implemented (iqhip_set_ascertainment refuses it):
-    // such runs keep the CPU kernels
-    if (!model_factory->unobserved_ptns.empty() && params->hip_devices.size() > 1) return false;
+    // +ASC on a pattern-sharded engine (-hipdevs with several GPUs): the unobserved constant patterns (at most nstates of them)
+    // must all lie on the last shard, which any alignment worth sharding satisfies
+    if (!model_factory->unobserved_ptns.empty() && params->hip_devices.size() > 1 &&
+        aln->getNPattern() < params->hip_devices.size() * 64) return false;
     // the reference's SIMD dispatch cases (phylotreesse.cpp:262-357: binary, DNA, protein, codon) and, through the engine's
     // exact embedding, the state counts it hands to its scalar kernel (:281-309; STATE_UNKNOWN = nstates, no mixtures)
     if (n != 2 && n != 4 && n != 20 && n != 64 && (model->isMixture() || aln->STATE_UNKNOWN != n)) return false;

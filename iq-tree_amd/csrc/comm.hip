@@ -43,7 +43,10 @@ Rccl &rccl() {
         const char *names[] = {getenv("IQHIP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char *n : names) {
             if (!n || !*n) continue;
-            R.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            // RTLD_LOCAL: librccl drags in librocm_smi64, whose global objects must not interpose with a second copy of that
+            // library that the process may load later (torch ships its own): with RTLD_GLOBAL a test order that made this
+            // dlopen come BEFORE `import torch` ended in a double free inside rocm_smi's static destructors at exit
+            R.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (R.handle) break;
             R.err = dlerror();
         }
@@ -193,8 +196,6 @@ extern "C" int iqhip_comm_init_rank(iqhip_engine *e, int nranks, int rank, const
     if (!e->shards.empty()) return set_error(IQHIP_ERR_INVALID, "a sharded engine has its own communicators");
     if (nranks < 1 || rank < 0 || rank >= nranks) return set_error(IQHIP_ERR_INVALID, "bad rank / rank count");
     if (e->comm) return set_error(IQHIP_ERR_INVALID, "engine already has a communicator");
-    if (e->n_unobs > 0)
-        return set_error(IQHIP_ERR_UNSUPPORTED, "+ASC corrections are applied on the host: not available on a sharded engine");
     Rccl *R;
     int rc = need_rccl(&R);
     if (rc) return rc;

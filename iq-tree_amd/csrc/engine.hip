@@ -428,10 +428,12 @@ extern "C" int iqhip_set_ascertainment(iqhip_engine *e, int64_t n_unobserved, do
     if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
     if (n_unobserved < 0 || n_unobserved >= e->nptn || (n_unobserved > 0 && !(nsites > 0.0)))
         return fail(IQHIP_ERR_INVALID, "iqhip_set_ascertainment: bad pattern count / site count");
-    if (n_unobserved > 0 && (e->comm || !e->shards.empty()))
-        return fail(IQHIP_ERR_UNSUPPORTED, "+ASC corrections are applied on the host: not available on a sharded engine");
+    if (!e->shards.empty()) return sharded::set_ascertainment(e, n_unobserved, nsites);
     e->n_unobs = n_unobserved;
     e->asc_nsites = nsites;
+    // one rank of a pattern-sharded run (iqhip_comm_init_rank): every rank passes the alignment's site count; the ranks
+    // that hold none of the unobserved patterns pass n_unobserved = 0 with nsites > 0
+    e->asc_active = n_unobserved > 0 || (e->comm && nsites > 0.0);
     e->pattern_lh_shift = 0.0;
     return IQHIP_OK;
 }
@@ -1423,7 +1425,7 @@ static int repair_lnl(iqhip_engine *e, double *lnl) {
 // prob_const; tree_lh -= nsites*log(1-prob_const), _pattern_lh[observed] -= log(1-prob_const)
 static int asc_finish_lnl(iqhip_engine *e, double *lnl) {
     e->pattern_lh_shift = 0.0;
-    if (e->n_unobs == 0) return IQHIP_OK;
+    if (!e->asc_active) return IQHIP_OK;
     const double pc = e->h_result[1];
     if (!(pc < 1.0 && pc >= 0.0))
         return fail(IQHIP_ERR_INVALID, "+ASC: prob_const outside [0,1) (the reference asserts here)");
@@ -1500,8 +1502,7 @@ extern "C" int iqhip_traverse_lnl_async(iqhip_engine *e, const iqhip_node_op *op
                                         iqhip_branch_end a, iqhip_branch_end b, double len) {
     if (e && !e->shards.empty())
         return fail(IQHIP_ERR_UNSUPPORTED, "a sharded engine reduces its results itself: use the synchronous calls");
-    if (e && e->n_unobs > 0)
-        return fail(IQHIP_ERR_UNSUPPORTED, "+ASC needs the synchronous calls (its correction is applied on the host)");
+    // (+ASC: result[1] then holds this engine's share of prob_const; the caller owns the correction, phylokernel.h:1009-1016)
     return submit_traverse(e, ops, nops, true, a, b, len);
 }
 
@@ -1535,6 +1536,10 @@ extern "C" int iqhip_derv_async(iqhip_engine *e, double len) {
     if (!e->theta_valid) return fail(IQHIP_ERR_INVALID, "iqhip_derv: theta not computed");
     if (!(len >= 0.0)) return fail(IQHIP_ERR_INVALID, "negative or NaN branch length");
     const int nrows = e->n_unobs > 0 ? 5 : 2;  // +ASC: prob_const, df_const, ddf_const as well
+    if (e->asc_active && e->n_unobs == 0) {   // a shard without unobserved patterns contributes zeros to those three sums
+        if (e->d_result == e->d_result_own) e->h_result[2] = e->h_result[3] = e->h_result[4] = 0.0;
+        else HIPCHK(hipMemsetAsync(e->d_result + 2, 0, 3 * sizeof(double), e->stream));
+    }
     rc = ensure_slab_rows(e, nrows);
     if (rc) return rc;
     const int nwaves = (int)e->ntiles;
@@ -1548,13 +1553,13 @@ extern "C" int iqhip_derv(iqhip_engine *e, double len, double *df, double *ddf) 
     if (e && !e->shards.empty()) return sharded::derv(e, len, df, ddf);
     int rc = iqhip_derv_async(e, len);
     if (rc) return rc;
-    rc = comm_allreduce(e, 2);
+    rc = comm_allreduce(e, e->asc_active ? 5 : 2);
     if (rc) return rc;
-    rc = read_result(e, e->n_unobs > 0 ? 5 : 2);
+    rc = read_result(e, e->asc_active ? 5 : 2);
     if (rc) return rc;
     double a = e->h_result[0], b = e->h_result[1];
     if (isnan(a) || isinf(a)) { a = 0.0; b = 0.0; }  // phylokernel.h:647-651
-    if (e->n_unobs > 0) {  // phylokernel.h:719-724
+    if (e->asc_active) {  // phylokernel.h:719-724
         const double prob_const = 1.0 - e->h_result[2];
         const double df_frac = e->h_result[3] / prob_const, ddf_frac = e->h_result[4] / prob_const;
         a += e->asc_nsites * df_frac;
@@ -1584,9 +1589,12 @@ int newton_state_alloc(iqhip_engine *e) {
 int newton_chain_enqueue(iqhip_engine *e, int nsteps) {
     const int nwaves = (int)e->ntiles;
     for (int k = 0; k < nsteps; k++) {
-        if (launch_derv_at_state(e, nwaves) != hipSuccess || launch_reduce(e, 0, 2, nwaves) != hipSuccess)
+        const int rows = e->asc_active ? 5 : 2;   // (+ASC: prob_const, df_const, ddf_const ride along)
+        if (e->asc_active && e->n_unobs == 0 && hipMemsetAsync(e->d_result + 2, 0, 3 * sizeof(double), e->stream) != hipSuccess)
+            return set_error(IQHIP_ERR_HIP, "Newton chain: memset failed");
+        if (launch_derv_at_state(e, nwaves) != hipSuccess || launch_reduce(e, 0, e->n_unobs > 0 ? 5 : 2, nwaves) != hipSuccess)
             return set_error(IQHIP_ERR_HIP, "Newton chain: launch failed");
-        int rc = comm_allreduce(e, 2);
+        int rc = comm_allreduce(e, rows);
         if (rc) return rc;
         if (launch_newton_state_update(e) != hipSuccess) return set_error(IQHIP_ERR_HIP, "Newton chain: launch failed");
     }
@@ -1601,7 +1609,7 @@ int eng_newton_begin(iqhip_engine *e, double xguess, double x1, double x2, doubl
     if (!e->theta_valid) return set_error(IQHIP_ERR_INVALID, "Newton: theta not computed");
     rc = newton_state_alloc(e);
     if (rc) return rc;
-    rc = ensure_slab_rows(e, 2);
+    rc = ensure_slab_rows(e, 5);
     if (rc) return rc;
     if (launch_newton_state_init(e, xguess, x1, x2, xacc, max_steps) != hipSuccess)
         return set_error(IQHIP_ERR_HIP, "Newton chain: launch failed");
@@ -1610,7 +1618,9 @@ int eng_newton_begin(iqhip_engine *e, double xguess, double x1, double x2, doubl
 int eng_newton_eval_enqueue(iqhip_engine *e) {
     if (use_device(e) != hipSuccess) return set_error(IQHIP_ERR_HIP, "hipSetDevice");
     const int nwaves = (int)e->ntiles;
-    if (launch_derv_at_state(e, nwaves) != hipSuccess || launch_reduce(e, 0, 2, nwaves) != hipSuccess)
+    if (e->asc_active && e->n_unobs == 0 && hipMemsetAsync(e->d_result + 2, 0, 3 * sizeof(double), e->stream) != hipSuccess)
+        return set_error(IQHIP_ERR_HIP, "Newton chain: memset failed");
+    if (launch_derv_at_state(e, nwaves) != hipSuccess || launch_reduce(e, 0, e->n_unobs > 0 ? 5 : 2, nwaves) != hipSuccess)
         return set_error(IQHIP_ERR_HIP, "Newton chain: launch failed");
     return IQHIP_OK;
 }
@@ -1674,7 +1684,7 @@ static int newton_chain(iqhip_engine *e, double xguess, double x1, double x2, do
                         double *optx, double *d2l, int *nsteps) {
     int rc = newton_state_alloc(e);
     if (rc) return rc;
-    rc = ensure_slab_rows(e, 2);
+    rc = ensure_slab_rows(e, 5);
     if (rc) return rc;
     HIPCHK(launch_newton_state_init(e, xguess, x1, x2, xacc, max_steps));
     // a typical solve converges in 3..5 evaluations: enqueue that many before looking
@@ -1719,7 +1729,6 @@ extern "C" int iqhip_newton_branch(iqhip_engine *e, double xguess, double x1, do
     if (rc) return rc;
     if (!e->theta_valid) return fail(IQHIP_ERR_INVALID, "iqhip_newton_branch: theta not computed");
     if (newton_use_chain(e)) {
-        if (e->n_unobs > 0) return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_newton_branch: the enqueued chain form has no +ASC correction; use iqhip_derv");
         return newton_chain(e, xguess, x1, x2, xacc, max_steps, optx, d2l, nsteps);
     }
     HIPCHK(launch_newton(e, xguess, x1, x2, xacc, max_steps, e->d_result));
@@ -1730,7 +1739,6 @@ extern "C" int iqhip_newton_branch(iqhip_engine *e, double xguess, double x1, do
     if (status == 3) return fail(IQHIP_ERR_INVALID, "Maximum number of iterations exceeded in minimizeNewton");
     if (status == 4) {  // the grid barrier gave up (another kernel held the CUs): the chain needs no barrier
         (void)hipStreamSynchronize(e->stream);
-        if (e->n_unobs > 0) return fail(IQHIP_ERR_HIP, "Newton solve: the exchange between workgroups timed out (+ASC has no chain form)");
         return newton_chain(e, xguess, x1, x2, xacc, max_steps, optx, d2l, nsteps);
     }
     if (optx) *optx = e->h_result[0];
@@ -1750,7 +1758,7 @@ extern "C" int iqhip_optimize_branch(iqhip_engine *e, const iqhip_node_op *ops, 
     iqhip_branch_end none = {0, -1, 0};
     int rc = IQHIP_OK;
     if (e && newton_use_chain(e)) {
-        if (e->n_unobs > 0) return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_optimize_branch: the enqueued chain form has no +ASC correction; use iqhip_derv");
+
         // sharded rank: node updates (their sum_scale rows all-reduced), theta, then the enqueued Newton chain
         if (nops > 0) {
             rc = iqhip_update_partials(e, ops, nops, sum_scale);
@@ -1784,7 +1792,6 @@ extern "C" int iqhip_optimize_branch(iqhip_engine *e, const iqhip_node_op *ops, 
     if (status == 3) return fail(IQHIP_ERR_INVALID, "Maximum number of iterations exceeded in minimizeNewton");
     if (status == 4) {  // grid barrier gave up: theta was built by the first evaluation, finish with the chain
         (void)hipStreamSynchronize(e->stream);
-        if (e->n_unobs > 0) return fail(IQHIP_ERR_HIP, "Newton solve: the exchange between workgroups timed out (+ASC has no chain form)");
         return newton_chain(e, xguess, x1, x2, xacc, max_steps, optx, d2l, nsteps);
     }
     if (optx) *optx = r[0];
@@ -2283,7 +2290,7 @@ extern "C" int iqhip_lnl_from_theta(iqhip_engine *e, double len, double *lnl) {
     if (e && !e->shards.empty()) return sharded::lnl_from_theta(e, len, lnl);
     int rc = iqhip_lnl_from_theta_async(e, len);
     if (rc) return rc;
-    rc = comm_allreduce(e, 1);
+    rc = comm_allreduce(e, e->asc_active ? 2 : 1);
     if (rc) return rc;
     rc = read_result(e, 2);
     if (rc) return rc;
@@ -2402,7 +2409,7 @@ extern "C" int iqhip_fetch_pattern_lh(iqhip_engine *e, double *out) {
     HIPCHK(use_device(e));
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(out, e->d_pattern_lh, sizeof(double) * (size_t)e->nptn, hipMemcpyDeviceToHost));
-    if (e->n_unobs > 0) {  // phylokernel.h:1013-1014: observed patterns only
+    if (e->asc_active) {  // phylokernel.h:1013-1014: observed patterns only
         const int64_t nobs = e->nptn - e->n_unobs;
         for (int64_t p = 0; p < nobs; p++) out[p] -= e->pattern_lh_shift;
         for (int64_t p = nobs; p < e->nptn; p++) out[p] = 0.0;

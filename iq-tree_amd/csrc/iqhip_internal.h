@@ -250,6 +250,10 @@ struct iqhip_engine {
     // +ASC (phylokernel.h:868-909,655-725,1124-1187): the last n_unobs patterns are the unobserved
     // constant patterns; asc_nsites = aln->getNSite()
     int64_t n_unobs = 0;
+    // pattern-sharded runs: the correction is active on EVERY shard / rank (asc_active), while the unobserved patterns --
+    // appended at the end of the alignment -- sit on the last one(s) only (n_unobs = this engine's share, possibly 0);
+    // the sums prob_const / df_const / ddf_const travel with the result vector through the all-reduce
+    bool asc_active = false;
     double asc_nsites = 0.0;
     double pattern_lh_shift = 0.0;        // log(1 - prob_const) of the last lnL evaluation
     const int16_t *theta_a_sc = nullptr;  // scale counters of the ends theta was built from
@@ -566,6 +570,7 @@ int reserve(iqhip_engine *p, int nvectors);
 int release(iqhip_engine *p, uint64_t key);
 int rekey(iqhip_engine *p, uint64_t old_key, uint64_t new_key);
 int set_alignment(iqhip_engine *p, const uint8_t *states, const double *ptn_freq, const double *ptn_invar);
+int set_ascertainment(iqhip_engine *p, int64_t n_unobserved, double nsites);
 int set_ptn_array(iqhip_engine *p, const double *v, bool invar);
 int set_model(iqhip_engine *p, int nclass, const int32_t *cat_class, const double *eval, const double *evec,
               const double *inv_evec, const double *rates, const double *props, int state_unknown, const double *tip);
@@ -618,7 +623,7 @@ hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, d
 // (skipped once state->done), state update from result[0..1]
 hipError_t launch_newton_state_init(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps);
 hipError_t launch_derv_at_state(iqhip_engine *e, int nwaves);
-hipError_t launch_newton_state_update(iqhip_engine *e);
+hipError_t launch_newton_state_update(iqhip_engine *e);   // (+ASC: result[2..4] and asc_nsites enter the update)
 
 // kernels_sweep.hip: a whole sweep of a 4-state engine in one launch; posts: [2][kNewtonPostEpochs][grid][2] all-ones
 int sweep4_grid(const iqhip_engine *e);

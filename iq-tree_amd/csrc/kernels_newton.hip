@@ -960,11 +960,20 @@ __global__ void k_newton_state_init(NewtonState *st, double xguess, double x1, d
     }
 }
 
-__global__ void k_newton_state_update(NewtonState *st, const double *result) {
+// asc_nsites > 0: +ASC -- result[2..4] are prob_const, df_const, ddf_const summed over all shards (phylokernel.h:719-724)
+__global__ void k_newton_state_update(NewtonState *st, const double *result, double asc_nsites) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         NewtonState s = *st;
         if (!s.done) {
-            newton_update(s, result[0], result[1]);
+            double df = result[0], ddf = result[1];
+            if (asc_nsites > 0.0) {
+                if (isnan(df) || isinf(df)) { df = 0.0; ddf = 0.0; }   // (phylokernel.h:647-651 comes first)
+                const double prob_const = 1.0 - result[2];
+                const double df_frac = result[3] / prob_const, ddf_frac = result[4] / prob_const;
+                df += asc_nsites * df_frac;
+                ddf += asc_nsites * (ddf_frac + df_frac * df_frac);
+            }
+            newton_update(s, df, ddf);
             *st = s;
         }
     }
@@ -981,7 +990,7 @@ hipError_t launch_derv_at_state(iqhip_engine *e, int nwaves) {
 }
 
 hipError_t launch_newton_state_update(iqhip_engine *e) {
-    hipLaunchKernelGGL(k_newton_state_update, dim3(1), dim3(64), 0, e->stream, e->d_nstate, e->d_result);
+    hipLaunchKernelGGL(k_newton_state_update, dim3(1), dim3(64), 0, e->stream, e->d_nstate, e->d_result, e->asc_active ? e->asc_nsites : 0.0);
     return hipGetLastError();
 }
 

@@ -95,7 +95,7 @@ hipError_t launch_pattern_lh_cat(iqhip_engine *e, double len, double *out) {
 hipError_t launch_pattern_lh_scaled(iqhip_engine *e, const int16_t *sc_a, const int16_t *sc_b, double *out) {
     const int64_t P = e->nptn_pad;
     hipLaunchKernelGGL(k_pattern_lh_scaled, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, e->stream, e->d_pattern_lh,
-                       sc_a, sc_b, e->nptn - e->n_unobs, P, e->n_unobs > 0 ? e->pattern_lh_shift : 0.0, out);
+                       sc_a, sc_b, e->nptn - e->n_unobs, P, e->asc_active ? e->pattern_lh_shift : 0.0, out);
     return hipGetLastError();
 }
 

@@ -181,6 +181,48 @@ int set_ptn_array(iqhip_engine *p, const double *v, bool invar) {
     return IQHIP_OK;
 }
 
+// +ASC: the unobserved constant patterns are the LAST n_unobserved patterns of the alignment, i.e. of the last shard;
+// every shard knows that the correction is active and how many sites there are
+int set_ascertainment(iqhip_engine *p, int64_t n_unobserved, double nsites) {
+    const size_t last = p->shards.size() - 1;
+    if (n_unobserved >= p->shard_first[last + 1] - p->shard_first[last])
+        return bad(IQHIP_ERR_INVALID, "iqhip_set_ascertainment: the unobserved patterns must fit the last shard");
+    for (size_t g = 0; g < p->shards.size(); g++) {
+        iqhip_engine *c = p->shards[g];
+        c->n_unobs = g == last ? n_unobserved : 0;
+        c->asc_nsites = nsites;
+        c->asc_active = n_unobserved > 0;
+        c->pattern_lh_shift = 0.0;
+    }
+    p->n_unobs = n_unobserved;
+    p->asc_nsites = nsites;
+    p->asc_active = n_unobserved > 0;
+    p->pattern_lh_shift = 0.0;
+    return IQHIP_OK;
+}
+
+// phylokernel.h:1009-1016 / 1183-1186 on the summed prob_const; the shards learn the shift for their _pattern_lh views
+static int asc_finish(iqhip_engine *p, double prob_const, double *lnl) {
+    if (!p->asc_active) return IQHIP_OK;
+    if (!(prob_const < 1.0 && prob_const >= 0.0))
+        return bad(IQHIP_ERR_INVALID, "+ASC: prob_const outside [0,1) (the reference asserts here)");
+    const double lp = log(1.0 - prob_const);
+    *lnl -= p->asc_nsites * lp;
+    p->pattern_lh_shift = lp;
+    for (iqhip_engine *c : p->shards) c->pattern_lh_shift = lp;
+    return IQHIP_OK;
+}
+
+// phylokernel.h:647-651, then :719-724 on the summed {prob_const, df_const, ddf_const} = v[2..4]
+static void asc_derv(const iqhip_engine *p, std::vector<double> &v) {
+    if (isnan(v[0]) || isinf(v[0])) v[0] = v[1] = 0.0;
+    if (!p->asc_active) return;
+    const double prob_const = 1.0 - v[2];
+    const double df_frac = v[3] / prob_const, ddf_frac = v[4] / prob_const;
+    v[0] += p->asc_nsites * df_frac;
+    v[1] += p->asc_nsites * (ddf_frac + df_frac * df_frac);
+}
+
 int traverse(iqhip_engine *p, const iqhip_node_op *ops, int nops, bool has_root, iqhip_branch_end a, iqhip_branch_end b,
              double len, double *sum_scale, double *lnl) {
     if (nops < 0 || (nops > 0 && !ops)) return bad(IQHIP_ERR_INVALID, "bad ops array");
@@ -204,6 +246,8 @@ int traverse(iqhip_engine *p, const iqhip_node_op *ops, int nops, bool has_root,
                 r += s;
             }
         }
+        rc = asc_finish(p, v[1], &r);
+        if (rc) return rc;
         if (lnl) *lnl = r;
     }
     return IQHIP_OK;
@@ -224,9 +268,9 @@ int derv(iqhip_engine *p, double len, double *df, double *ddf) {
         if (rc) return rc;
     }
     std::vector<double> v;
-    int rc = reduce_results(p, 2, v);
+    int rc = reduce_results(p, p->asc_active ? 5 : 2, v);
     if (rc) return rc;
-    if (isnan(v[0]) || isinf(v[0])) v[0] = v[1] = 0.0;  // phylokernel.h:647-651
+    asc_derv(p, v);
     if (df) *df = v[0];
     if (ddf) *ddf = v[1];
     return IQHIP_OK;
@@ -238,7 +282,7 @@ int lnl_from_theta(iqhip_engine *p, double len, double *lnl) {
         if (rc) return rc;
     }
     std::vector<double> v;
-    int rc = reduce_results(p, 1, v);
+    int rc = reduce_results(p, p->asc_active ? 2 : 1, v);
     if (rc) return rc;
     double r = v[0];
     if (isnan(r) || isinf(r)) {
@@ -249,6 +293,10 @@ int lnl_from_theta(iqhip_engine *p, double len, double *lnl) {
             if (rc) return rc;
             r += s;
         }
+    }
+    if (p->asc_active) {
+        rc = asc_finish(p, v[1], &r);
+        if (rc) return rc;
     }
     if (lnl) *lnl = r;
     return IQHIP_OK;
@@ -281,7 +329,7 @@ int optimize_branch(iqhip_engine *p, const iqhip_node_op *ops, int nops, bool bu
                     rc = eng_newton_eval_enqueue(c);
                     if (rc) return rc;
                 }
-                rc = comm_group_allreduce(p->shards, 2);
+                rc = comm_group_allreduce(p->shards, p->asc_active ? 5 : 2);
                 if (rc) return rc;
                 for (iqhip_engine *c : p->shards) {
                     rc = eng_newton_update_enqueue(c);
@@ -305,8 +353,9 @@ int optimize_branch(iqhip_engine *p, const iqhip_node_op *ops, int nops, bool bu
                 if (rc) return rc;
             }
             std::vector<double> v;
-            rc = reduce_results(p, 2, v);
+            rc = reduce_results(p, p->asc_active ? 5 : 2, v);
             if (rc) return rc;
+            if (p->asc_active) asc_derv(p, v);
             newton_update(st, v[0], v[1]);
         }
     }

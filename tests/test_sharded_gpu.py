@@ -126,8 +126,8 @@ def test_sharded_shard_ranges_and_refusals(pkg, synth, oracle):
     assert lib.iqhip_create_sharded(C.byref(e), two, 2, pkg.REDUCE_RCCL, 4, 4, 1000, 8) == 2
     assert b"distinct devices" in lib.iqhip_last_error()
     assert lib.iqhip_create_sharded(C.byref(e), two, 2, pkg.REDUCE_HOST, 4, 4, 100, 8) == 2
-    with pytest.raises(pkg.HostError):
-        ts.set_ascertainment(4, 100.0)
+    with pytest.raises(pkg.HostError):   # +ASC: the unobserved patterns must fit the last shard (here: 320 patterns)
+        ts.set_ascertainment(400, 100.0)
         ts.compute_likelihood()
 
 
@@ -202,3 +202,67 @@ def test_newton_chain_on_a_plain_engine(pkg, synth, oracle, n, ncat, seq_type, n
             res[mode] = (t.optimize_one_branch(a, b), t.num_derv_calls - c0)
         (lh, ch), (ld, cd) = res[False], res[True]
         assert cd == ch and abs(ld - lh) <= 1e-12 * max(lh, 1e-6), (a, b, res)
+
+
+@pytest.mark.parametrize("n,ncat,seq_type", [(4, 4, 0), (20, 4, 1)])
+@pytest.mark.parametrize("setup", ["host2", "host3", "rccl1", "comm1"])
+def test_sharded_ascertainment_bias_correction(pkg, synth, oracle, n, ncat, seq_type, setup):
+    """+ASC on pattern shards (phylokernel.h:655-725, 868-909, 1124-1187): the unobserved constant patterns sit at the end of
+    the alignment, i.e. on the last shard; prob_const / df_const / ddf_const travel with the result vector through the
+    reduction and every shard / the front applies the correction to the summed values.  lnL, per-pattern lnL,
+    derivatives, lnL from theta, the Newton chain (device state machine with the correction inside its update kernel,
+    or the host-advanced one) and a whole optimizeAllBranches against the oracle and a plain engine."""
+    model = synth.gtr_model(alpha=0.9, ncat=ncat) if n == 4 else synth.random_reversible_model(n, 51, alpha=0.9, ncat=ncat)
+    nwk = synth.random_tree_newick(9, 52, 0.02, 0.15)
+    st = synth.simulate_alignment(nwk, model, 2500, 53)
+    pat, freq = synth.compress_patterns(st)
+    const = np.all(pat == pat[0][None, :], axis=0)
+    pat, freq = np.ascontiguousarray(pat[:, ~const]), freq[~const].copy()
+    nun, nsites = n, float(freq.sum())
+    pat = np.ascontiguousarray(np.concatenate([pat, np.tile(np.arange(n, dtype=np.uint8)[None, :], (9, 1))], axis=1))
+    freq = np.concatenate([freq, np.zeros(n)])
+    ot = oracle.OracleTree(nwk, n, seq_type, pat, freq, None, model, n_unobs=nun, nsites=nsites)
+
+    def plain():
+        t = pkg.PhyloTree(nwk)
+        t.set_alignment(n, seq_type, pat, freq)
+        t.set_ascertainment(nun, nsites)
+        t.set_model(model)
+        t.attach_engine(0)
+        return t
+    t = plain()
+    if setup == "comm1":
+        ts = plain()
+        ts.attach_comm(1, 0, pkg.comm_unique_id())
+    else:
+        devices, mode = {"host2": ([0, 0], pkg.REDUCE_HOST), "host3": ([0, 0, 0], pkg.REDUCE_HOST), "rccl1": ([0], pkg.REDUCE_RCCL)}[setup]
+        ts = pkg.PhyloTree(nwk)
+        ts.set_alignment(n, seq_type, pat, freq)
+        ts.set_ascertainment(nun, nsites)
+        ts.set_model(model)
+        ts.attach_engine_sharded(devices, mode)
+    ref, (a, b) = ot.likelihood()
+    lnl, plh = ts.compute_likelihood(want_pattern_lh=True)
+    assert abs(lnl - ref) <= LNL_RTOL * abs(ref)
+    _, oplh = ot.branch_lnl(a, b)
+    np.testing.assert_allclose(plh[:-nun], oplh[:-nun], rtol=1e-10, atol=1e-10)
+    for (x, y) in [(a, b), (t.num_leaves, t.neighbors(t.num_leaves)[0][0])]:
+        assert abs(ts.compute_likelihood_branch(x, y) - ref) <= LNL_RTOL * abs(ref)
+        ts.reset_theta()
+        df, ddf = ts.compute_likelihood_derv(x, y)
+        odf, oddf = ot.derv(x, y)
+        assert abs(df - odf) <= 1e-9 * max(1.0, abs(odf)) + 1e-12 * abs(oddf)
+        assert abs(ddf - oddf) <= 1e-9 * abs(oddf)
+        o, _ = ot.lnl_from_theta(x, y)
+        assert abs(ts.compute_likelihood_from_buffer() - o) <= LNL_RTOL * abs(o)
+        # one branch: the chain's optimum and evaluation count are the oracle's minimizeNewton's
+        ref_x, _, pts, status = ot.minimize_newton(x, y, 1e-6, ot.length(x, y), 100.0, 1e-6, 100)
+        c0 = ts.num_derv_calls
+        got = ts.optimize_one_branch(x, y)
+        assert status == "ok" and ts.num_derv_calls - c0 == len(pts)
+        assert abs(got - ref_x) <= 1e-9 * max(1.0, ref_x)
+        ot.set_length(x, y, got)
+        t.set_branch_length(x, y, got, clear_reverse=True)
+        ref, _ = ot.likelihood()
+    v, vs = t.optimize_all_branches(iterations=2, tolerance=1e-6), ts.optimize_all_branches(iterations=2, tolerance=1e-6)
+    assert abs(v - vs) <= 1e-9 * abs(v)
