@@ -267,7 +267,9 @@ int iqhip_fetch_theta(iqhip_engine *e, double *out /* nptn*block, ref layout */)
  * phylotree.cpp:2901-2924), then optimises the length of branch (a, b) as iqhip_optimize_branch does and
  * evaluates computeLikelihoodFromBuffer at the optimum.  results[t].lnl excludes the lh_scale_factor terms;
  * sum_scale receives the per-op values of all tasks, concatenated in task order.  +ASC is not supported.
- * On a sharded engine the tasks run one after the other (every Newton step needs its own all-reduce). */
+ * On a sharded engine (iqhip_create_sharded, iqhip_comm_init_rank) the tasks advance side by side as well: per Newton
+ * step one derivative launch for all tasks and ONE all-reduce of 2 * ntasks doubles (chunks of 64 tasks, the same on
+ * every rank); +ASC engines run the tasks one after the other. */
 typedef struct iqhip_branch_task {
     const iqhip_node_op *ops;
     int32_t nops;

@@ -228,6 +228,7 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
     comm_destroy(e);
     if (e->d_result_dev) hipFree(e->d_result_dev);
     if (e->d_nstate) hipFree(e->d_nstate);
+    if (e->d_bstates) hipFree(e->d_bstates);
     if (e->h_nstate) hipHostFree(e->h_nstate);
     if (e->stream) hipStreamSynchronize(e->stream);
     for (auto &s : e->slabs) {
@@ -1437,6 +1438,10 @@ static int asc_finish_lnl(iqhip_engine *e, double *lnl) {
 
 namespace iqhip {
 int eng_read_result(iqhip_engine *e, int ndoubles) { return read_result(e, ndoubles); }
+int eng_submit_updates(iqhip_engine *e, const iqhip_node_op *ops, int nops, const std::vector<int> *segs) {
+    iqhip_branch_end none = {0, -1, 0};
+    return submit_traverse(e, ops, nops, false, none, none, 0.0, /*skip_reduce=*/false, segs);
+}
 int eng_repair_lnl(iqhip_engine *e, double *lnl) { return repair_lnl(e, lnl); }
 }  // namespace iqhip
 
@@ -2094,9 +2099,204 @@ extern "C" int iqhip_optimize_sweep(iqhip_engine *e, const iqhip_sweep_step *ste
     return IQHIP_OK;
 }
 
-// iqhip_optimize_branch_batch on a sharded engine (a rank with a communicator, or the single-process front): the
-// tasks run one after the other through the chain form -- every Newton step of every task needs its own all-reduce,
-// so nothing is gained by putting them side by side in one kernel; what stays is one C call per batch.
+// ---------------------------------------------------------------------------------------
+// Batched chain: iqhip_optimize_branch_batch on pattern shards.  The m tasks of a chunk advance side by side: per Newton
+// step ONE derivative launch (grid.y = task, branch length read from the task's device-resident state machine), ONE
+// k_reduce over 2m slab rows, ONE all-reduce of 2m doubles, ONE update kernel (thread = task); tasks that have converged
+// do nothing.  Identical sums on every rank => identical iterates, so all ranks leave the loop together.
+// ---------------------------------------------------------------------------------------
+namespace iqhip {
+static BatchChain batch_chain_of(const iqhip_engine *e, int m) {
+    return BatchChain{e->d_theta_batch, (size_t)e->nptn_pad * e->block, e->d_bstates, m};
+}
+
+int eng_batch_prepare(iqhip_engine *e, const iqhip_branch_task *tasks, int m, const NewtonState *init) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    if (2 * m > e->result_cap) return set_error(IQHIP_ERR_INVALID, "too many tasks in one chunk");
+    rc = ensure_slab_rows(e, std::max(5, 2 * m));
+    if (rc) return rc;
+    const size_t theta_stride = (size_t)e->nptn_pad * e->block;
+    if ((size_t)m * theta_stride > e->theta_batch_cap) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->d_theta_batch) hipFree(e->d_theta_batch);
+        e->d_theta_batch = nullptr;
+        e->theta_batch_cap = 0;
+        HIPCHK(dmalloc(&e->d_theta_batch, (size_t)m * theta_stride));
+        e->theta_batch_cap = (size_t)m * theta_stride;
+    }
+    if (m > e->bstates_cap) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->d_bstates) hipFree(e->d_bstates);
+        e->d_bstates = nullptr;
+        e->bstates_cap = 0;
+        HIPCHK(hipMalloc((void **)&e->d_bstates, sizeof(NewtonState) * (size_t)m));
+        e->bstates_cap = m;
+    }
+    for (int t = 0; t < m; t++) {
+        DevBranch br;
+        rc = build_branch(e, tasks[t].a, tasks[t].b, 0.0, -1, &br);
+        if (rc) return rc;
+        double *slot = e->d_theta_batch + (size_t)t * theta_stride;
+        if (e->mfma) HIPCHK(launch_stream_mfma(e, 1, &br, 0.0, (int)e->ntiles, nullptr, -1, slot));
+        else HIPCHK(launch_theta4(e, br, slot));
+    }
+    return eng_batch_states_write(e, m, init);
+}
+
+int eng_batch_states_write(iqhip_engine *e, int m, const NewtonState *in) {
+    if (use_device(e) != hipSuccess) return set_error(IQHIP_ERR_HIP, "hipSetDevice");
+    // (pageable source: the copy has left the host buffer when the call returns)
+    if (hipMemcpyAsync(e->d_bstates, in, sizeof(NewtonState) * (size_t)m, hipMemcpyHostToDevice, e->stream) != hipSuccess)
+        return set_error(IQHIP_ERR_HIP, "batched chain: state upload failed");
+    return IQHIP_OK;
+}
+
+int eng_batch_states_read(iqhip_engine *e, int m, NewtonState *out) {
+    if (use_device(e) != hipSuccess) return set_error(IQHIP_ERR_HIP, "hipSetDevice");
+    if (hipMemcpyAsync(out, e->d_bstates, sizeof(NewtonState) * (size_t)m, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess)
+        return set_error(IQHIP_ERR_HIP, "batched chain: state read failed");
+    e->staging_busy = false;
+    return IQHIP_OK;
+}
+
+int eng_batch_eval_enqueue(iqhip_engine *e, int m) {
+    if (use_device(e) != hipSuccess) return set_error(IQHIP_ERR_HIP, "hipSetDevice");
+    const BatchChain bc = batch_chain_of(e, m);
+    const int nwaves = (int)e->ntiles;
+    const hipError_t s = e->mfma ? launch_stream_mfma(e, 2, nullptr, 0.0, nwaves, nullptr, -1, nullptr, &bc)
+                                 : launch_derv4(e, 0.0, nwaves, nullptr, &bc);
+    if (s != hipSuccess || launch_reduce(e, 0, 2 * m, nwaves) != hipSuccess)
+        return set_error(IQHIP_ERR_HIP, "batched chain: launch failed");
+    return IQHIP_OK;
+}
+
+int eng_batch_update_enqueue(iqhip_engine *e, int m) {
+    if (use_device(e) != hipSuccess) return set_error(IQHIP_ERR_HIP, "hipSetDevice");
+    if (launch_newton_state_update_batch(e, e->d_bstates, m) != hipSuccess)
+        return set_error(IQHIP_ERR_HIP, "batched chain: launch failed");
+    return IQHIP_OK;
+}
+
+int eng_batch_lnl_enqueue(iqhip_engine *e, int m) {
+    if (use_device(e) != hipSuccess) return set_error(IQHIP_ERR_HIP, "hipSetDevice");
+    const BatchChain bc = batch_chain_of(e, m);
+    const int nwaves = (int)e->ntiles;
+    const hipError_t s = e->mfma ? launch_stream_mfma(e, 3, nullptr, 0.0, nwaves, nullptr, -1, nullptr, &bc)
+                                 : launch_lnl_theta4(e, 0.0, nwaves, &bc);
+    if (s != hipSuccess || launch_reduce(e, 0, 2 * m, nwaves) != hipSuccess)
+        return set_error(IQHIP_ERR_HIP, "batched chain: launch failed");
+    return IQHIP_OK;
+}
+}  // namespace iqhip
+
+// tasks per chunk of the batched chain: the same on every rank (the ranks' collectives must pair up), so a fixed number
+// and not what the free memory of this device suggests
+static int batch_chain_chunk(int ntasks) {
+    int chunk = std::min(ntasks, 64);
+    if (const char *bc = getenv("IQHIP_BATCH_CHUNK")) chunk = std::max(1, std::min(chunk, atoi(bc)));
+    return chunk;
+}
+
+static int batch_task_check(const iqhip_branch_task &k) {
+    if (k.nops < 0 || (k.nops > 0 && !k.ops)) return fail(IQHIP_ERR_INVALID, "bad ops array in a task");
+    if (!(k.x1 >= 0.0) || !(k.x2 > k.x1) || !(k.xacc > 0.0) || k.max_steps < 1 || !(k.xguess >= 0.0))
+        return fail(IQHIP_ERR_INVALID, "iqhip_optimize_branch_batch: bad bounds / tolerance / step count");
+    return IQHIP_OK;
+}
+
+static int batch_task_results(const std::vector<NewtonState> &st, int m, iqhip_branch_result *results) {
+    for (int t = 0; t < m; t++) {
+        if (st[t].status == 2) return fail(IQHIP_ERR_INVALID, "Wrong computeFuncDerv (non-finite derivative)");
+        if (st[t].status == 3) return fail(IQHIP_ERR_INVALID, "Maximum number of iterations exceeded in minimizeNewton");
+        results[t].optx = st[t].result;
+        results[t].d2l = st[t].d2l;
+        results[t].nsteps = st[t].neval;
+        results[t].status = 0;
+    }
+    return IQHIP_OK;
+}
+
+// a rank with a communicator: node updates of all tasks in one submission, then the batched chain
+static int optimize_branch_batch_comm(iqhip_engine *e, const iqhip_branch_task *tasks, int ntasks, double *sum_scale,
+                                      iqhip_branch_result *results) {
+    int rc = check_ready(e);
+    if (rc) return rc;
+    std::vector<iqhip_node_op> all;
+    std::vector<int> segs(ntasks);
+    for (int t = 0; t < ntasks; t++) {
+        rc = batch_task_check(tasks[t]);
+        if (rc) return rc;
+        segs[t] = tasks[t].nops;
+        all.insert(all.end(), tasks[t].ops, tasks[t].ops + tasks[t].nops);
+    }
+    const int total_ops = (int)all.size();
+    if (total_ops + 2 > e->result_cap) return fail(IQHIP_ERR_INVALID, "too many node updates in one submission");
+    iqhip_branch_end none = {0, -1, 0};
+    if (total_ops > 0) {
+        rc = submit_traverse(e, all.data(), total_ops, false, none, none, 0.0, /*skip_reduce=*/false, &segs);
+        if (rc) return rc;
+        rc = comm_allreduce(e, 2 + total_ops);
+        if (rc) return rc;
+        rc = read_result(e, 2 + total_ops);
+        if (rc) return rc;
+        if (sum_scale)
+            for (int k = 0; k < total_ops; k++) sum_scale[k] = e->h_result[2 + k];
+    }
+    const int chunk = batch_chain_chunk(ntasks);
+    std::vector<NewtonState> st((size_t)chunk);
+    for (int first = 0; first < ntasks; first += chunk) {
+        const int m = std::min(chunk, ntasks - first);
+        int max_steps = 1;
+        for (int t = 0; t < m; t++) {
+            const iqhip_branch_task &k = tasks[first + t];
+            newton_init(st[t], k.xguess, k.x1, k.x2, k.xacc, k.max_steps);
+            max_steps = std::max(max_steps, k.max_steps);
+        }
+        rc = eng_batch_prepare(e, tasks + first, m, st.data());
+        if (rc) return rc;
+        int enq = 0;
+        for (;;) {
+            const int steps = enq == 0 ? std::min(4, max_steps + 1) : 2;
+            for (int k = 0; k < steps; k++) {
+                rc = eng_batch_eval_enqueue(e, m);
+                if (!rc) rc = comm_allreduce(e, 2 * m);
+                if (!rc) rc = eng_batch_update_enqueue(e, m);
+                if (rc) return rc;
+            }
+            enq += steps;
+            rc = eng_batch_states_read(e, m, st.data());
+            if (rc) return rc;
+            bool all_done = true;
+            for (int t = 0; t < m; t++) all_done = all_done && st[t].done;
+            if (all_done) break;
+            if (enq > max_steps + 2) return fail(IQHIP_ERR_INVALID, "Newton chain did not terminate");
+        }
+        rc = batch_task_results(st, m, results + first);
+        if (rc) return rc;
+        // lnL of every task at its accepted length: one launch, one reduction, one all-reduce
+        rc = eng_batch_lnl_enqueue(e, m);
+        if (!rc) rc = comm_allreduce(e, 2 * m);
+        if (!rc) rc = read_result(e, 2 * m);
+        if (rc) return rc;
+        std::vector<double> lnl((size_t)m);
+        for (int t = 0; t < m; t++) lnl[t] = e->h_result[2 * t];
+        for (int t = 0; t < m; t++) {
+            results[first + t].lnl = lnl[t];
+            if (isnan(lnl[t]) || isinf(lnl[t])) {   // phylokernel.h:1091-1109: redo this task alone (same decision on every rank)
+                const iqhip_branch_task &k = tasks[first + t];
+                rc = iqhip_compute_theta(e, k.a, k.b);
+                if (!rc) rc = iqhip_lnl_from_theta(e, results[first + t].optx, &results[first + t].lnl);
+                if (rc) return rc;
+            }
+        }
+    }
+    return IQHIP_OK;
+}
+
+// iqhip_optimize_branch_batch, one task after the other through the chain form (IQHIP_BATCH_SEQUENTIAL=1: the form the
+// batched chain is tested against)
 static int optimize_branch_batch_sequential(iqhip_engine *e, const iqhip_branch_task *tasks, int ntasks,
                                             double *sum_scale, iqhip_branch_result *results) {
     size_t off = 0;
@@ -2119,7 +2319,14 @@ extern "C" int iqhip_optimize_branch_batch(iqhip_engine *e, const iqhip_branch_t
                                            double *sum_scale, iqhip_branch_result *results) {
     if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
     if (!tasks || !results || ntasks < 1) return fail(IQHIP_ERR_INVALID, "bad task array");
-    if (!e->shards.empty() || e->comm) return optimize_branch_batch_sequential(e, tasks, ntasks, sum_scale, results);
+    const char *seq_env = getenv("IQHIP_BATCH_SEQUENTIAL");   // (read per call: the tests compare the two forms)
+    const bool sequential = (seq_env && atoi(seq_env) != 0) || e->asc_active;   // (+ASC: 5-row results, one task at a time)
+    if (!e->shards.empty())
+        return sequential ? optimize_branch_batch_sequential(e, tasks, ntasks, sum_scale, results)
+                          : sharded::optimize_branch_batch(e, tasks, ntasks, sum_scale, results);
+    if (e->comm)
+        return sequential ? optimize_branch_batch_sequential(e, tasks, ntasks, sum_scale, results)
+                          : optimize_branch_batch_comm(e, tasks, ntasks, sum_scale, results);
     int rc = check_ready(e);
     if (rc) return rc;
     if (e->n_unobs > 0) return fail(IQHIP_ERR_UNSUPPORTED, "iqhip_optimize_branch_batch: +ASC is not supported");

@@ -364,6 +364,8 @@ struct iqhip_engine {
     int comm_nranks = 1, comm_rank = 0;
     double *d_result_dev = nullptr;  // device-memory result vector of a comm engine (the default one is mapped host memory)
     iqhip::NewtonState *d_nstate = nullptr, *h_nstate = nullptr;  // Newton state machine: device copy / pinned host copy
+    iqhip::NewtonState *d_bstates = nullptr;                      // batched chain: one state machine per task
+    int bstates_cap = 0;
     // ---- single-process sharding (sharded.hip): this object owns no device memory, it fronts `shards`
     // (pattern ranges [shard_first[g], shard_first[g+1]) on the devices of iqhip_create_sharded)
     std::vector<iqhip_engine *> shards;
@@ -555,12 +557,22 @@ int comm_use_device_result(iqhip_engine *e);  // switch the engine to a device-m
 
 // engine.hip internals the sharded front drives its shards with
 int eng_read_result(iqhip_engine *e, int ndoubles);   // D2H of the result vector (if it is device memory) + stream sync
+// node updates, asynchronous; segs: op counts of independent groups (each runs on its own workgroups)
+int eng_submit_updates(iqhip_engine *e, const iqhip_node_op *ops, int nops, const std::vector<int> *segs);
 int eng_repair_lnl(iqhip_engine *e, double *lnl);     // phylokernel.h:848-866 on this engine's _pattern_lh -> its own sum
 int newton_state_alloc(iqhip_engine *e);
 int newton_state_read(iqhip_engine *e);               // -> e->h_nstate (syncs the stream)
 int eng_newton_begin(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps);
 int eng_newton_eval_enqueue(iqhip_engine *e);         // derivative kernel at state->rts + k_reduce -> result[0..1]
 int eng_newton_update_enqueue(iqhip_engine *e);       // state machine step from result[0..1]
+// batched chain (iqhip_optimize_branch_batch on sharded engines): m tasks side by side, ONE reduction of 2m rows and
+// hence one all-reduce of 2m doubles per Newton step.  prepare: theta of every task into its slot + the initial states
+int eng_batch_prepare(iqhip_engine *e, const iqhip_branch_task *tasks, int m, const NewtonState *init);
+int eng_batch_eval_enqueue(iqhip_engine *e, int m);   // derivative kernels at states[t].rts + k_reduce -> result[0..2m)
+int eng_batch_update_enqueue(iqhip_engine *e, int m); // state machines step from result[0..2m)
+int eng_batch_lnl_enqueue(iqhip_engine *e, int m);    // lnL at states[t].result -> result[2t]
+int eng_batch_states_read(iqhip_engine *e, int m, NewtonState *out);        // (syncs the stream)
+int eng_batch_states_write(iqhip_engine *e, int m, const NewtonState *in);
 
 // sharded.hip -- the single-process multi-device front (iqhip_create_sharded); every public entry point of
 // engine.hip forwards here when e->shards is non-empty
@@ -582,6 +594,8 @@ int lnl_from_theta(iqhip_engine *p, double len, double *lnl);
 int optimize_branch(iqhip_engine *p, const iqhip_node_op *ops, int nops, bool build_theta, iqhip_branch_end a,
                     iqhip_branch_end b, double xguess, double x1, double x2, double xacc, int max_steps,
                     double *sum_scale, double *optx, double *d2l, int *nsteps);
+int optimize_branch_batch(iqhip_engine *p, const iqhip_branch_task *tasks, int ntasks, double *sum_scale,
+                          iqhip_branch_result *results);
 int fetch_scale_num(iqhip_engine *p, uint64_t key, int16_t *out);
 int fetch_pattern_lh(iqhip_engine *p, double *out, int kind, iqhip_branch_end a, iqhip_branch_end b);  // kind 0 plain, 1 scaled
 int fetch_vec(iqhip_engine *p, uint64_t key, bool theta, double *out);
@@ -598,9 +612,17 @@ int synchronize(iqhip_engine *p);
 // with a root branch) instead of a k_reduce launch
 hipError_t launch_traverse4(iqhip_engine *e, const int *seg_table, int nsegs, bool has_load, const DevBranch *root, int nwaves,
                             int fold_rows = -1);
-hipError_t launch_theta4(iqhip_engine *e, const DevBranch &br);
-hipError_t launch_derv4(iqhip_engine *e, double len, int nwaves, const NewtonState *st = nullptr);
-hipError_t launch_lnl_theta4(iqhip_engine *e, double len, int nwaves);
+// BatchChain: the batched form of the enqueued Newton chain (iqhip_optimize_branch_batch on sharded engines) -- task t
+// (blockIdx.y) has theta at theta + t * theta_stride, its state machine at states[t] and slab rows 2t, 2t + 1
+struct BatchChain {
+    const double *theta;
+    size_t theta_stride;
+    const NewtonState *states;
+    int ntasks;
+};
+hipError_t launch_theta4(iqhip_engine *e, const DevBranch &br, double *theta_out = nullptr);
+hipError_t launch_derv4(iqhip_engine *e, double len, int nwaves, const NewtonState *st = nullptr, const BatchChain *bc = nullptr);
+hipError_t launch_lnl_theta4(iqhip_engine *e, double len, int nwaves, const BatchChain *bc = nullptr);
 hipError_t launch_reduce(iqhip_engine *e, int first_row, int nrows, int nwaves);
 
 // kernels_newton.hip
@@ -624,6 +646,7 @@ hipError_t launch_newton(iqhip_engine *e, double xguess, double x1, double x2, d
 hipError_t launch_newton_state_init(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps);
 hipError_t launch_derv_at_state(iqhip_engine *e, int nwaves);
 hipError_t launch_newton_state_update(iqhip_engine *e);   // (+ASC: result[2..4] and asc_nsites enter the update)
+hipError_t launch_newton_state_update_batch(iqhip_engine *e, NewtonState *states, int ntasks);   // from result[2t], result[2t+1]
 
 // kernels_sweep.hip: a whole sweep of a 4-state engine in one launch; posts: [2][kNewtonPostEpochs][grid][2] all-ones
 int sweep4_grid(const iqhip_engine *e);
@@ -651,7 +674,9 @@ hipError_t launch_leaf_tables(iqhip_engine *e, const TabJob *d_jobs, int njobs);
 size_t leaf_table_doubles(const iqhip_engine *e);          // doubles per (leaf child) table: ncat * state_unknown * n
 int mfma2_fixed_lds_doubles(int n);
 // mode 0: branch lnL, 1: theta, 2: df/ddf from theta, 3: lnL from theta
+// theta_out (mode 1): write theta there instead of the engine's buffer; bc (modes 2, 3): batched chain, see BatchChain
 hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, double len, int nwaves,
-                              const NewtonState *st = nullptr, int fold_rows = -1);
+                              const NewtonState *st = nullptr, int fold_rows = -1, double *theta_out = nullptr,
+                              const BatchChain *bc = nullptr);
 
 }  // namespace iqhip

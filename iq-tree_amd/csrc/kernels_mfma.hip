@@ -1524,6 +1524,7 @@ struct StreamMArgs {
     int ncat;
     double len;
     const NewtonState *st;    // a step of the enqueued Newton chain: len = st->rts, nothing to do once st->done
+    size_t theta_stride;      // > 0: batched chain, blockIdx.y = task (own theta, state, pair of slab rows)
     FoldArgs fold;            // the last workgroup sums the slab itself (no k_reduce launch)
 };
 
@@ -1533,9 +1534,21 @@ __global__ __launch_bounds__(256) void k_stream_mfma(const StreamMArgs A) {
     const int N = A.n, B = A.n * A.ncat;
     double *s_v0 = smem, *s_v1 = smem + B, *s_v2 = smem + 2 * B;
     double len = A.len;
-    if (A.st) {
-        if (A.st->done) return;
-        len = A.st->rts;
+    const NewtonState *st = A.st;
+    const double *theta_in = A.theta;
+    double *slab = A.slab;
+    if (A.theta_stride) {
+        theta_in += (size_t)blockIdx.y * A.theta_stride;
+        slab += (size_t)2 * blockIdx.y * A.nwaves;
+        st += blockIdx.y;
+    }
+    if (st) {
+        if (MODE == 2) {
+            if (st->done) return;
+            len = st->rts;
+        } else {
+            len = st->result;   // (lnL at the accepted length, after the chain has finished)
+        }
     }
     if (MODE != 1) {
         for (int t = threadIdx.x; t < B; t += 256) {
@@ -1569,7 +1582,7 @@ __global__ __launch_bounds__(256) void k_stream_mfma(const StreamMArgs A) {
         }
         if (MODE == 1) return;
     } else {
-        const double *th = A.theta + tbase;
+        const double *th = theta_in + tbase;
         for (int e = g; e < B; e += 4) {
             const double t = th[(size_t)e * 16 + p];
             lh = fma(s_v0[e], t, lh);
@@ -1600,16 +1613,16 @@ __global__ __launch_bounds__(256) void k_stream_mfma(const StreamMArgs A) {
         const double ddfp = fma(-dfp, dfp, d2 * inv);
         const double wa = wave_sum_m(mine ? dfp * f : 0.0), wb = wave_sum_m(mine ? ddfp * f : 0.0);
         if (lane == 0) {
-            fold_store(&A.slab[tile], wa);
-            fold_store(&A.slab[(size_t)A.nwaves + tile], wb);
+            fold_store(&slab[tile], wa);
+            fold_store(&slab[(size_t)A.nwaves + tile], wb);
         }
         if (asc) {  // phylokernel.h:655-725
             const double w2 = wave_sum_m(unobs ? lhi : 0.0), w3 = wave_sum_m(unobs ? d1 : 0.0),
                          w4 = wave_sum_m(unobs ? d2 : 0.0);
             if (lane == 0) {
-                A.slab[(size_t)2 * A.nwaves + tile] = w2;
-                A.slab[(size_t)3 * A.nwaves + tile] = w3;
-                A.slab[(size_t)4 * A.nwaves + tile] = w4;
+                slab[(size_t)2 * A.nwaves + tile] = w2;
+                slab[(size_t)3 * A.nwaves + tile] = w3;
+                slab[(size_t)4 * A.nwaves + tile] = w4;
             }
         }
     } else {
@@ -1621,21 +1634,23 @@ __global__ __launch_bounds__(256) void k_stream_mfma(const StreamMArgs A) {
             pc = (ssc >= 1 ? lh * kScalingThreshold : lh) + iv;
         }
         const double plh = log(fabs(lh + iv));
-        if (g == 0) A.pattern_lh[ptn] = plh;
+        if (g == 0 && A.pattern_lh) A.pattern_lh[ptn] = plh;
         const double wa = wave_sum_m(mine ? plh * f : 0.0);
         const double wpc = asc ? wave_sum_m(pc) : 0.0;
         if (lane == 0) {
-            fold_store(&A.slab[tile], wa);
-            fold_store(&A.slab[(size_t)A.nwaves + tile], wpc);
+            fold_store(&slab[tile], wa);
+            fold_store(&slab[(size_t)A.nwaves + tile], wpc);
         }
     }
     if (A.fold.enabled) fold_tail(A.fold);
 }
 
 hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, double len, int nwaves,
-                              const NewtonState *st, int fold_rows) {
+                              const NewtonState *st, int fold_rows, double *theta_out, const BatchChain *bc) {
     StreamMArgs A;
-    A.st = st;
+    A.st = bc ? bc->states : st;
+    A.theta_stride = bc ? bc->theta_stride : 0;
+    if (bc) fold_rows = -1;
     A.fold.slab = e->d_slab;
     A.fold.result = e->d_result;
     A.fold.ticket = e->d_fold_ticket;
@@ -1653,8 +1668,8 @@ hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, do
     A.props = e->d_props;
     A.freq = e->d_freq;
     A.invar = e->d_invar;
-    A.theta = e->d_theta;
-    A.pattern_lh = e->d_pattern_lh;
+    A.theta = bc ? const_cast<double *>(bc->theta) : (theta_out ? theta_out : e->d_theta);
+    A.pattern_lh = bc ? nullptr : e->d_pattern_lh;
     A.slab = e->d_slab;
     A.ntiles = e->ntiles;
     A.nptn = e->nptn;
@@ -1665,13 +1680,13 @@ hipError_t launch_stream_mfma(iqhip_engine *e, int mode, const DevBranch *br, do
     A.n = e->n;
     A.ncat = e->ncat;
     A.len = len;
-    const int grid = (int)((e->ntiles + 3) / 4);
+    const dim3 grid((unsigned)((e->ntiles + 3) / 4), (unsigned)(bc ? bc->ntasks : 1));
     const size_t lds = (size_t)3 * e->block * sizeof(double);
     switch (mode) {
-        case 0: hipLaunchKernelGGL(k_stream_mfma<0>, dim3(grid), dim3(256), lds, e->stream, A); break;
-        case 1: hipLaunchKernelGGL(k_stream_mfma<1>, dim3(grid), dim3(256), lds, e->stream, A); break;
-        case 2: hipLaunchKernelGGL(k_stream_mfma<2>, dim3(grid), dim3(256), lds, e->stream, A); break;
-        default: hipLaunchKernelGGL(k_stream_mfma<3>, dim3(grid), dim3(256), lds, e->stream, A); break;
+        case 0: hipLaunchKernelGGL(k_stream_mfma<0>, grid, dim3(256), lds, e->stream, A); break;
+        case 1: hipLaunchKernelGGL(k_stream_mfma<1>, grid, dim3(256), lds, e->stream, A); break;
+        case 2: hipLaunchKernelGGL(k_stream_mfma<2>, grid, dim3(256), lds, e->stream, A); break;
+        default: hipLaunchKernelGGL(k_stream_mfma<3>, grid, dim3(256), lds, e->stream, A); break;
     }
     return hipGetLastError();
 }

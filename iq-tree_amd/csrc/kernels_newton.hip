@@ -979,6 +979,22 @@ __global__ void k_newton_state_update(NewtonState *st, const double *result, dou
     }
 }
 
+// batched chain: thread t advances task t's state machine from result[2t], result[2t + 1]
+__global__ void k_newton_state_update_batch(NewtonState *st, const double *result, int ntasks) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntasks) return;
+    NewtonState s = st[t];
+    if (s.done) return;
+    newton_update(s, result[2 * t], result[2 * t + 1]);
+    st[t] = s;
+}
+
+hipError_t launch_newton_state_update_batch(iqhip_engine *e, NewtonState *states, int ntasks) {
+    hipLaunchKernelGGL(k_newton_state_update_batch, dim3((unsigned)((ntasks + 63) / 64)), dim3(64), 0, e->stream, states,
+                       e->d_result, ntasks);
+    return hipGetLastError();
+}
+
 hipError_t launch_newton_state_init(iqhip_engine *e, double xguess, double x1, double x2, double xacc, int max_steps) {
     hipLaunchKernelGGL(k_newton_state_init, dim3(1), dim3(64), 0, e->stream, e->d_nstate, xguess, x1, x2, xacc, max_steps);
     return hipGetLastError();

@@ -634,12 +634,13 @@ __global__ __launch_bounds__(256) void k_theta4(DevBranch br, const double *__re
     store_vec4<C>(theta, tile, lane, Th);
 }
 
-hipError_t launch_theta4(iqhip_engine *e, const DevBranch &br) {
+hipError_t launch_theta4(iqhip_engine *e, const DevBranch &br, double *theta_out) {
     const int grid = (int)((e->ntiles + 3) / 4);
+    double *const theta = theta_out ? theta_out : e->d_theta;
 #define IQ_THETA(Cv)                                                                        \
     case Cv:                                                                                \
         hipLaunchKernelGGL(k_theta4<Cv>, dim3(grid), dim3(256), 0, e->stream, br, e->d_tip, \
-                           e->state_unknown, e->d_theta, e->ntiles);                       \
+                           e->state_unknown, theta, e->ntiles);                          \
         break;
     switch (e->ncat) {
         IQ_THETA(1) IQ_THETA(2) IQ_THETA(3) IQ_THETA(4) IQ_THETA(5) IQ_THETA(6) IQ_THETA(7) IQ_THETA(8)
@@ -660,12 +661,21 @@ __global__ __launch_bounds__(256) void k_theta_reduce4(
     const double *__restrict__ freq, const double *__restrict__ invar,
     double *__restrict__ pattern_lh, double *__restrict__ slab, int64_t ntiles, int64_t nptn,
     int nwaves, int64_t nobs, const int16_t *__restrict__ a_sc, const int16_t *__restrict__ b_sc,
-    const NewtonState *st) {
+    const NewtonState *st, size_t theta_stride) {
     constexpr int B = 4 * C;
     __shared__ double s_v0[B], s_v1[B], s_v2[B];
+    if (theta_stride) {   // batched chain (blockIdx.y = task): own theta, own state, own pair of slab rows
+        theta += (size_t)blockIdx.y * theta_stride;
+        slab += (size_t)2 * blockIdx.y * nwaves;
+        st += blockIdx.y;
+    }
     if (st) {  // a step of the enqueued Newton chain: the branch length is the state's current iterate
-        if (st->done) return;
-        len = st->rts;
+        if (MODE == 0) {
+            if (st->done) return;
+            len = st->rts;
+        } else {
+            len = st->result;   // (lnL at the accepted length, after the chain has finished)
+        }
     }
     if (threadIdx.x < B) {
         const int c = threadIdx.x >> 2, i = threadIdx.x & 3;
@@ -725,7 +735,7 @@ __global__ __launch_bounds__(256) void k_theta_reduce4(
             pc = (ssc >= 1 ? lh * kScalingThreshold : lh) + iv;
         }
         const double plh = log(fabs(lh + iv));
-        pattern_lh[ptn] = plh;
+        if (pattern_lh) pattern_lh[ptn] = plh;
         const double a = (ptn < nobs) ? plh * f : 0.0;
         const double wa = wave_sum(a);
         const double wpc = (nobs < nptn) ? wave_sum(pc) : 0.0;
@@ -737,14 +747,19 @@ __global__ __launch_bounds__(256) void k_theta_reduce4(
 }
 
 template <int MODE>
-static hipError_t launch_theta_reduce(iqhip_engine *e, double len, int nwaves, const NewtonState *st = nullptr) {
+static hipError_t launch_theta_reduce(iqhip_engine *e, double len, int nwaves, const NewtonState *st = nullptr,
+                                      const BatchChain *bc = nullptr) {
     const int grid = (int)((e->ntiles + 3) / 4);
+    const double *theta = bc ? bc->theta : e->d_theta;
+    double *plh = bc ? nullptr : e->d_pattern_lh;
+    const size_t stride = bc ? bc->theta_stride : 0;
+    const int ny = bc ? bc->ntasks : 1;
 #define IQ_TR(Cv)                                                                              \
     case Cv:                                                                                   \
-        hipLaunchKernelGGL((k_theta_reduce4<Cv, MODE>), dim3(grid), dim3(256), 0, e->stream,   \
-                           e->d_theta, e->d_eval, e->d_rates, e->d_props, len, e->d_freq,      \
-                           e->d_invar, e->d_pattern_lh, e->d_slab, e->ntiles, e->nptn, nwaves,  \
-                           e->nptn - e->n_unobs, e->theta_a_sc, e->theta_b_sc, st);            \
+        hipLaunchKernelGGL((k_theta_reduce4<Cv, MODE>), dim3(grid, ny), dim3(256), 0, e->stream, \
+                           theta, e->d_eval, e->d_rates, e->d_props, len, e->d_freq,           \
+                           e->d_invar, plh, e->d_slab, e->ntiles, e->nptn, nwaves,             \
+                           e->nptn - e->n_unobs, e->theta_a_sc, e->theta_b_sc, st, stride);    \
         break;
     switch (e->ncat) {
         IQ_TR(1) IQ_TR(2) IQ_TR(3) IQ_TR(4) IQ_TR(5) IQ_TR(6) IQ_TR(7) IQ_TR(8)
@@ -754,11 +769,11 @@ static hipError_t launch_theta_reduce(iqhip_engine *e, double len, int nwaves, c
     return hipGetLastError();
 }
 
-hipError_t launch_derv4(iqhip_engine *e, double len, int nwaves, const NewtonState *st) {
-    return launch_theta_reduce<0>(e, len, nwaves, st);
+hipError_t launch_derv4(iqhip_engine *e, double len, int nwaves, const NewtonState *st, const BatchChain *bc) {
+    return launch_theta_reduce<0>(e, len, nwaves, bc ? bc->states : st, bc);
 }
-hipError_t launch_lnl_theta4(iqhip_engine *e, double len, int nwaves) {
-    return launch_theta_reduce<1>(e, len, nwaves);
+hipError_t launch_lnl_theta4(iqhip_engine *e, double len, int nwaves, const BatchChain *bc) {
+    return launch_theta_reduce<1>(e, len, nwaves, bc ? bc->states : nullptr, bc);
 }
 
 // ---------------------------------------------------------------------------------------

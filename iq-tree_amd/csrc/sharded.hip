@@ -367,6 +367,124 @@ int optimize_branch(iqhip_engine *p, const iqhip_node_op *ops, int nops, bool bu
     return IQHIP_OK;
 }
 
+// iqhip_optimize_branch_batch on the front: the tasks' node updates in one submission per shard, then the batched chain
+// (engine.hip eng_batch_*): per Newton step one derivative launch per shard for all tasks and ONE reduction of 2m values
+// across the shards (grouped all-reduce, or the host's sum with the state machines advanced on the host)
+int optimize_branch_batch(iqhip_engine *p, const iqhip_branch_task *tasks, int ntasks, double *sum_scale,
+                          iqhip_branch_result *results) {
+    std::vector<iqhip_node_op> all;
+    std::vector<int> segs((size_t)ntasks);
+    for (int t = 0; t < ntasks; t++) {
+        const iqhip_branch_task &k = tasks[t];
+        if (k.nops < 0 || (k.nops > 0 && !k.ops)) return bad(IQHIP_ERR_INVALID, "bad ops array in a task");
+        if (!(k.x1 >= 0.0) || !(k.x2 > k.x1) || !(k.xacc > 0.0) || k.max_steps < 1 || !(k.xguess >= 0.0))
+            return bad(IQHIP_ERR_INVALID, "iqhip_optimize_branch_batch: bad bounds / tolerance / step count");
+        segs[t] = k.nops;
+        all.insert(all.end(), k.ops, k.ops + k.nops);
+    }
+    const int total_ops = (int)all.size();
+    int rc = IQHIP_OK;
+    std::vector<double> v;
+    if (total_ops > 0) {
+        for (iqhip_engine *c : p->shards) {
+            rc = eng_submit_updates(c, all.data(), total_ops, &segs);
+            if (rc) return rc;
+        }
+        rc = reduce_results(p, 2 + total_ops, v);
+        if (rc) return rc;
+        if (sum_scale)
+            for (int k = 0; k < total_ops; k++) sum_scale[k] = v[2 + k];
+    }
+    int chunk = std::min(ntasks, 64);
+    if (const char *bc = getenv("IQHIP_BATCH_CHUNK")) chunk = std::max(1, std::min(chunk, atoi(bc)));
+    const bool rccl = p->reduce_mode == IQHIP_REDUCE_RCCL;
+    std::vector<NewtonState> st((size_t)chunk);
+    for (int first = 0; first < ntasks; first += chunk) {
+        const int m = std::min(chunk, ntasks - first);
+        int max_steps = 1;
+        for (int t = 0; t < m; t++) {
+            const iqhip_branch_task &k = tasks[first + t];
+            newton_init(st[t], k.xguess, k.x1, k.x2, k.xacc, k.max_steps);
+            max_steps = std::max(max_steps, k.max_steps);
+        }
+        for (iqhip_engine *c : p->shards) {
+            rc = eng_batch_prepare(c, tasks + first, m, st.data());
+            if (rc) return rc;
+        }
+        auto all_done = [&] {
+            for (int t = 0; t < m; t++)
+                if (!st[t].done) return false;
+            return true;
+        };
+        if (rccl) {
+            int enq = 0;
+            for (;;) {
+                const int steps = enq == 0 ? std::min(4, max_steps + 1) : 2;
+                for (int k = 0; k < steps; k++) {
+                    for (iqhip_engine *c : p->shards) {
+                        rc = eng_batch_eval_enqueue(c, m);
+                        if (rc) return rc;
+                    }
+                    rc = comm_group_allreduce(p->shards, 2 * m);
+                    if (rc) return rc;
+                    for (iqhip_engine *c : p->shards) {
+                        rc = eng_batch_update_enqueue(c, m);
+                        if (rc) return rc;
+                    }
+                }
+                enq += steps;
+                rc = eng_batch_states_read(p->shards[0], m, st.data());
+                if (rc) return rc;
+                if (all_done()) break;
+                if (enq > max_steps + 2) return bad(IQHIP_ERR_INVALID, "Newton chain did not terminate");
+            }
+        } else {
+            for (int guard = 0; !all_done(); guard++) {
+                if (guard > max_steps + 2) return bad(IQHIP_ERR_INVALID, "Newton loop did not terminate");
+                for (iqhip_engine *c : p->shards) {
+                    if (guard > 0) rc = eng_batch_states_write(c, m, st.data());
+                    if (!rc) rc = eng_batch_eval_enqueue(c, m);
+                    if (rc) return rc;
+                }
+                rc = reduce_results(p, 2 * m, v);
+                if (rc) return rc;
+                for (int t = 0; t < m; t++)
+                    if (!st[t].done) newton_update(st[t], v[2 * t], v[2 * t + 1]);
+            }
+            for (iqhip_engine *c : p->shards) {   // (the lnL launch reads the accepted lengths from the states)
+                rc = eng_batch_states_write(c, m, st.data());
+                if (rc) return rc;
+            }
+        }
+        for (int t = 0; t < m; t++) {
+            if (st[t].status == 2) return bad(IQHIP_ERR_INVALID, "Wrong computeFuncDerv (non-finite derivative)");
+            if (st[t].status == 3) return bad(IQHIP_ERR_INVALID, "Maximum number of iterations exceeded in minimizeNewton");
+            iqhip_branch_result &r = results[first + t];
+            r.optx = st[t].result;
+            r.d2l = st[t].d2l;
+            r.nsteps = st[t].neval;
+            r.status = 0;
+        }
+        for (iqhip_engine *c : p->shards) {
+            rc = eng_batch_lnl_enqueue(c, m);
+            if (rc) return rc;
+        }
+        rc = reduce_results(p, 2 * m, v);
+        if (rc) return rc;
+        const std::vector<double> lnl(v);
+        for (int t = 0; t < m; t++) {
+            iqhip_branch_result &r = results[first + t];
+            r.lnl = lnl[2 * t];
+            if (isnan(r.lnl) || isinf(r.lnl)) {   // rare: redo this task alone, with the per-shard repair
+                rc = compute_theta(p, tasks[first + t].a, tasks[first + t].b);
+                if (!rc) rc = lnl_from_theta(p, r.optx, &r.lnl);
+                if (rc) return rc;
+            }
+        }
+    }
+    return IQHIP_OK;
+}
+
 int fetch_scale_num(iqhip_engine *p, uint64_t key, int16_t *out) {
     for (size_t g = 0; g < p->shards.size(); g++) {
         int rc = iqhip_fetch_scale_num(p->shards[g], key, out + p->shard_first[g]);

@@ -6,6 +6,8 @@ csrc/comm.hip).  A one-GPU box cannot give RCCL two ranks (it refuses two ranks 
     in-stream ncclAllReduce of the device result vector, the enqueued Newton chain with its update kernel) runs with
     ONE rank.
 Everything is compared with the oracle on the unsharded alignment and with a plain engine."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -167,6 +169,62 @@ def test_sharded_branch_optimisation_and_nni(pkg, synth, oracle, setup):
     ot2 = oracle.OracleTree(ts.tree_string(), 4, 0, ot.states, ot.freq, None, ot.model)
     ref, _ = ot2.likelihood()
     assert abs(vs - ref) <= 1e-8 * abs(ref)
+
+
+@pytest.mark.parametrize("n,ncat,seq_type,nptn", [(4, 4, 0, 1500), (20, 4, 1, 900)])
+@pytest.mark.parametrize("setup", ["host2", "host3", "rccl1", "comm1"])
+def test_batched_nni_tasks_share_one_reduction_per_newton_step(pkg, synth, oracle, monkeypatch, setup, n, ncat, seq_type, nptn):
+    """iqhip_optimize_branch_batch on pattern shards: the tasks advance side by side -- one derivative launch per shard
+    with the task as grid.y, ONE reduction / all-reduce of 2m doubles per Newton step, one update kernel -- instead of one
+    chain per task.  Same accepted lengths, evaluation counts and lnL as the one-task-at-a-time form
+    (IQHIP_BATCH_SEQUENTIAL=1) and as the plain engine's k_newton_batch; chunked batches (IQHIP_BATCH_CHUNK) too."""
+    t, ot, args = case(synth, oracle, pkg, 11, nptn, n, ncat, 7700 + n, seq_type=seq_type, mem_mode=pkg.LM_ALL_BRANCH)
+    nwk, n_, st_, pat, freq, invar, model = args
+    if setup == "comm1":
+        ts = pkg.PhyloTree(nwk)
+        ts.set_mem_mode(pkg.LM_ALL_BRANCH)
+        ts.set_alignment(n, seq_type, pat, freq, invar)
+        ts.set_model(model)
+        ts.attach_engine(0)
+        ts.attach_comm(1, 0, pkg.comm_unique_id())
+    else:
+        devices, mode = {"host2": ([0, 0], pkg.REDUCE_HOST), "host3": ([0, 0, 0], pkg.REDUCE_HOST), "rccl1": ([0], pkg.REDUCE_RCCL)}[setup]
+        ts = sharded_tree(pkg, args, devices, mode, mem_mode=pkg.LM_ALL_BRANCH)
+    t.compute_likelihood()
+    ts.compute_likelihood()
+    plain = t.evaluate_nnis_batch()
+    lib = pkg.libiqhip()
+
+    def collectives(run):   # all-reduces the rank issued while `run` ran (comm engines count them while timing is on)
+        if setup != "comm1":
+            return run(), None
+        lib.iqhip_timing_enable(ts.engine, 1)
+        avg, cnt = C.c_double(), C.c_int64()
+        lib.iqhip_timing_collective_read(ts.engine, C.byref(avg), C.byref(cnt), 1)
+        out = run()
+        lib.iqhip_timing_collective_read(ts.engine, C.byref(avg), C.byref(cnt), 1)
+        lib.iqhip_timing_enable(ts.engine, 0)
+        return out, cnt.value
+    monkeypatch.setenv("IQHIP_BATCH_SEQUENTIAL", "1")
+    seq, nseq = collectives(ts.evaluate_nnis_batch)
+    monkeypatch.delenv("IQHIP_BATCH_SEQUENTIAL")
+    side, nside = collectives(ts.evaluate_nnis_batch)
+    if setup == "comm1":   # 16 tasks: one all-reduce per Newton step of the slowest task (+ updates, lnL) instead of per task and step
+        assert nside * 6 <= nseq, (nside, nseq)
+    monkeypatch.setenv("IQHIP_BATCH_CHUNK", "3")
+    chunked = ts.evaluate_nnis_batch()
+    monkeypatch.delenv("IQHIP_BATCH_CHUNK")
+    assert len(plain) == len(seq) == len(side) == len(chunked) == 2 * (11 - 3)
+    for mp, ms, mb, mc in zip(plain, seq, side, chunked):
+        assert ms["new_len"] == mb["new_len"] == mc["new_len"], (ms, mb, mc)        # same sums in the same order: same iterates
+        assert abs(ms["newloglh"] - mb["newloglh"]) <= 1e-12 * abs(ms["newloglh"])
+        assert mb["newloglh"] == mc["newloglh"]
+        assert abs(mp["new_len"] - mb["new_len"]) <= 1e-8 * max(mp["new_len"], 1e-6)
+        assert abs(mp["newloglh"] - mb["newloglh"]) <= 1e-10 * abs(mp["newloglh"])
+    # the five-branch form goes through the same entry point
+    five, five_s = t.evaluate_nnis5_batch(), ts.evaluate_nnis5_batch()
+    for m, ms in zip(five, five_s):
+        assert abs(m["newloglh"] - ms["newloglh"]) <= 1e-9 * abs(m["newloglh"])
 
 
 def test_sharded_rell_and_uploads(pkg, synth, oracle):
