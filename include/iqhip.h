@@ -346,6 +346,13 @@ int iqhip_timing_plan_bytes(iqhip_engine *e, double *stored, double *loaded);
  * stream reaches the collective to its completion, i.e. including the wait for slower ranks. */
 int iqhip_timing_collective_read(iqhip_engine *e, double *avg_us, int64_t *count, int reset);
 
+/* Cherry tables (20 states x 4 categories, >= 8192 patterns; IQHIP_CHERRY_TABLES=0 switches them off): a node whose two
+ * children are leaves (computePartialLikelihood's leaf-leaf case, phylokernel.h:187-260) takes one of (STATE_UNKNOWN+1)^2
+ * values per pattern, so the engine computes that table once per (pair of taxa, pendant lengths, model) -- with the same
+ * kernels on a pseudo-alignment of all state pairs, hence the same bits -- and the traversal copies rows instead of issuing
+ * the node's three matrix products.  Counters since the engine was created: tables built, node updates answered. */
+int iqhip_debug_cherry_tables(iqhip_engine *e, int64_t *tables_built, int64_t *ops_from_tables);
+
 /* Debugging aid, no reference counterpart: a PLANNING-ONLY engine makes no HIP call and owns no device memory (its
  * vectors are distinct fake addresses).  iqhip_debug_plan turns an op list into the device descriptors exactly as
  * iqhip_update_partials would (key -> slab map, canonical child order, staging, LDS chunks, K2 table slots, look-ahead

@@ -34,7 +34,7 @@ IQHIP_SYMBOLS = [
     "iqhip_create_sharded", "iqhip_num_shards", "iqhip_shard_range", "iqhip_comm_unique_id", "iqhip_comm_init_rank",
     "iqhip_comm_size", "iqhip_update_partials_async", "iqhip_lnl_from_theta_async",
     "iqhip_newton_host_init", "iqhip_newton_host_update", "iqhip_newton_host_result",
-    "iqhip_debug_create_planner", "iqhip_debug_plan", "iqhip_timing_plan_bytes", "iqhip_timing_collective_read", "iqhip_optimize_sweep",
+    "iqhip_debug_create_planner", "iqhip_debug_plan", "iqhip_timing_plan_bytes", "iqhip_timing_collective_read", "iqhip_optimize_sweep", "iqhip_debug_cherry_tables",
 ]
 
 
@@ -143,6 +143,7 @@ def libiqhip():
     lib.iqhip_debug_create_planner.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.iqhip_timing_plan_bytes.argtypes = [vp, dp, dp]
     lib.iqhip_timing_collective_read.argtypes = [vp, dp, C.POINTER(C.c_int64), C.c_int]
+    lib.iqhip_debug_cherry_tables.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.iqhip_debug_plan.argtypes = [vp, C.POINTER(NodeOp), C.c_int]
     lib._iq_typed = True
     return lib

@@ -83,6 +83,7 @@ static void configure_engine(iqhip_engine *e, int device, int nstates, int nstat
     if (const char *h = getenv("IQHIP_MIXED_TOP")) e->mixed_top = atoi(h) != 0;
     if (const char *f = getenv("IQHIP_FOLD")) e->fold_reduce = atoi(f) != 0;
     if (const char *f = getenv("IQHIP_POLL")) e->poll_result = atoi(f) != 0;
+    if (const char *f = getenv("IQHIP_CHERRY_TABLES")) e->cherry_on = atoi(f) != 0;
     if (const char *sp = getenv("IQHIP_SPLIT")) e->split_target = atoi(sp);
     if (const char *kb = getenv("IQHIP_LDS_KB")) {
         int v = atoi(kb);
@@ -225,6 +226,9 @@ extern "C" void iqhip_destroy(iqhip_engine *e) {
     }
     use_device(e);
     if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->pair) iqhip_destroy(e->pair);   // (runs on this engine's stream, which it does not own)
+    e->pair = nullptr;
+    if (e->d_cherry_tab) hipFree(e->d_cherry_tab);
     comm_destroy(e);
     if (e->d_result_dev) hipFree(e->d_result_dev);
     if (e->d_nstate) hipFree(e->d_nstate);
@@ -269,6 +273,7 @@ extern "C" int iqhip_set_stream(iqhip_engine *e, void *hip_stream) {
     if (e->own_stream) hipStreamDestroy(e->stream);
     e->stream = (hipStream_t)hip_stream;
     e->own_stream = false;
+    if (e->pair) return iqhip_set_stream(e->pair, hip_stream);
     return IQHIP_OK;
 }
 
@@ -602,12 +607,64 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
     e->model_set = true;
     e->theta_valid = false;
     e->model_version++;
+    e->cherry_model_synced = false;
     return IQHIP_OK;
 }
 
 // embedded data: pad the caller's m-state system (m = n_user) to the n-state one the kernels run (see iqhip_engine::embed2):
 // eigenvalues (l_0 .. l_m-1, 0 ...), U = diag(U_m, I), U^-1 = diag(U_m^-1, I); tip rows of the m states padded with zeros;
 // internal state n = "missing" with the caller's unknown row, internal STATE_UNKNOWN = n + 1 (never present in the data)
+// ---------------------------------------------------------------------------------------
+// cherry tables (DevOp::cherry): which engines use them, and their pair engine
+// ---------------------------------------------------------------------------------------
+static bool cherry_candidate(const iqhip_engine *e) {
+    if (!e || !e->cherry_on || e->planner || !e->shards.empty() || e->ablate) return false;
+    if (!(e->mfma_pipelined_ok && e->n == 20 && e->n_user == 20 && e->ncat == 4) || e->leaf_tables || e->cat_split) return false;
+    return e->nptn_pad >= 8 * 1024;   // (a table costs one node update over <= 1024 patterns per new pair of lengths)
+}
+
+static int cherry_sync_model(iqhip_engine *e, const double *eval, const double *evec, const double *inv_evec,
+                             const double *rates, const double *props, int state_unknown, const double *tip) {
+    const int s2 = state_unknown + 1;
+    if (s2 * s2 > 1024) {   // (too many pairs of states: no tables)
+        if (e->pair) iqhip_destroy(e->pair);
+        e->pair = nullptr;
+        return IQHIP_OK;
+    }
+    if (e->pair && e->cherry_s2 != s2) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        iqhip_destroy(e->pair);
+        e->pair = nullptr;
+    }
+    int rc = IQHIP_OK;
+    if (!e->pair) {
+        const int npairs = s2 * s2;
+        rc = iqhip_create(&e->pair, e->device, 20, e->ncat, npairs, 2);
+        if (rc) return rc;
+        e->pair->cherry_on = false;
+        e->pair->check_plans = e->check_plans;
+        rc = iqhip_set_stream(e->pair, e->stream);
+        if (rc) return rc;
+        e->cherry_s2 = s2;
+        e->cherry_npairs = (int)e->pair->nptn_pad;
+        e->cherry_slot_of.clear();
+        e->cherry_slots.clear();
+    }
+    rc = set_model_common(e->pair, 1, nullptr, eval, evec, inv_evec, rates, props, state_unknown, tip);
+    if (rc) return rc;
+    if (!e->pair->aln_set) {
+        const int npairs = s2 * s2;
+        std::vector<uint8_t> st((size_t)2 * npairs);
+        for (int q = 0; q < npairs; q++) {
+            st[q] = (uint8_t)(q / s2);
+            st[(size_t)npairs + q] = (uint8_t)(q % s2);
+        }
+        const std::vector<double> ones((size_t)npairs, 1.0), zeros((size_t)npairs, 0.0);
+        rc = iqhip_set_alignment(e->pair, st.data(), ones.data(), zeros.data());
+    }
+    return rc;
+}
+
 static int set_model_binary(iqhip_engine *e, const double *eval, const double *evec, const double *inv_evec,
                             const double *rates, const double *props, int state_unknown, const double *tip) {
     if (!eval || !evec || !inv_evec || !rates || !props || !tip) return fail(IQHIP_ERR_INVALID, "null argument");
@@ -630,7 +687,12 @@ extern "C" int iqhip_set_model(iqhip_engine *e, const double *eval, const double
                                int state_unknown, const double *tip_partial_lh) {
     if (e && e->embed2 && e->shards.empty())
         return set_model_binary(e, eval, evec, inv_evec, rates, props, state_unknown, tip_partial_lh);
-    return set_model_common(e, 1, nullptr, eval, evec, inv_evec, rates, props, state_unknown, tip_partial_lh);
+    int rc = set_model_common(e, 1, nullptr, eval, evec, inv_evec, rates, props, state_unknown, tip_partial_lh);
+    if (!rc && cherry_candidate(e)) {
+        rc = cherry_sync_model(e, eval, evec, inv_evec, rates, props, state_unknown, tip_partial_lh);
+        e->cherry_model_synced = !rc && e->pair != nullptr;
+    }
+    return rc;
 }
 
 extern "C" int iqhip_set_mixture_model(iqhip_engine *e, int nclass, const int32_t *cat_class, const double *eval,
@@ -747,6 +809,13 @@ static int check_plan(iqhip_engine *e, int nops, int nsentinels) {
         if (!scs.count(d.ld_sc)) return bad(k, "ld_sc is not a counter slab / the dummy");
         if (!state_row(d.sl) || !state_row(d.sr)) return bad(k, "sl / sr is not a row of the state matrix");
         if (!table(d.tabL) || !table(d.tabR)) return bad(k, "tabL / tabR is not a K2 table slot");
+        if (d.cherry) {
+            const size_t cper = (size_t)e->cherry_npairs * e->block;
+            if (!e->d_cherry_tab || cper == 0 || d.cherry < e->d_cherry_tab || (size_t)(d.cherry - e->d_cherry_tab) % cper != 0 ||
+                (size_t)(d.cherry - e->d_cherry_tab) / cper >= e->cherry_cap || k >= nops || d.left_kind != CHILD_LEAF ||
+                d.right_kind != CHILD_LEAF)
+                return bad(k, "cherry is not a cherry-table slot of an op with two leaf children");
+        }
         if (k >= nops) continue;  // sentinels: pointers only
         if (d.dst == e->dummy.plh || d.dst_sc == e->dummy.sc) return bad(k, "a real op writes the dummy slab");
         const bool lk = d.left_kind == CHILD_LEAF || d.left_kind == CHILD_PF || d.left_kind == CHILD_HOLD ||
@@ -793,7 +862,8 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
     const std::vector<int> no_segs;
     const std::vector<int> &segs_in = explicit_segs ? *explicit_segs : no_segs;
     if (!len_ptrs && nops > 0 && e->last_plan_version == e->keymap_version && e->last_ops_in.size() == in_bytes &&
-        memcmp(e->last_ops_in.data(), ops, in_bytes) == 0 && !e->uploaded_plan.empty() && e->last_segs == segs_in) {
+        memcmp(e->last_ops_in.data(), ops, in_bytes) == 0 && !e->uploaded_plan.empty() && e->last_segs == segs_in &&
+        (!e->plan_uses_cherry || e->plan_cherry_model == e->model_version)) {
         *last_dst = e->last_plan_dst;
         return IQHIP_OK;
     }
@@ -1151,6 +1221,59 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         e->plan_tab_dirty = (int)dirty.size();
         e->plan_nleaf_tabs = (int)e->plan_tab_jobs.size();
     }
+    // cherry tables: an op whose two children are leaves reads its result out of the table of its pair of taxa
+    e->plan_cherry_jobs.clear();
+    e->plan_uses_cherry = false;
+    e->plan_cherry_model = e->model_version;
+    if (cherry_candidate(e) && e->mfma_pipelined && e->pair && e->cherry_model_synced && nops >= 8) {
+        const size_t per = (size_t)e->cherry_npairs * B;
+        const size_t want = (size_t)2 * e->ntaxa + 16;
+        if (e->cherry_cap < want) {
+            HIPCHK(hipStreamSynchronize(e->stream));
+            if (e->d_cherry_tab) hipFree(e->d_cherry_tab);
+            e->d_cherry_tab = nullptr;
+            e->cherry_cap = 0;
+            HIPCHK(dmalloc(&e->d_cherry_tab, want * per));
+            e->cherry_cap = want;
+            e->cherry_slot_of.clear();
+            e->cherry_slots.clear();
+        }
+        // room for every cherry a plan can hold; a search that has walked through more pairs than that starts over
+        if (e->cherry_slots.size() + (size_t)e->ntaxa / 2 + 1 > e->cherry_cap) {
+            e->cherry_slot_of.clear();
+            e->cherry_slots.clear();
+        }
+        const uint64_t stamp = ++e->cherry_stamp;
+        for (int k = 0; k < nops; k++) {
+            DevOp &d = e->h_ops[k];
+            if (d.left_kind != CHILD_LEAF || d.right_kind != CHILD_LEAF || d.left_len_p || d.right_len_p) continue;
+            if (e->top_cs2 && seg_of[k] == 0) continue;   // (the top stage's two-waves-per-tile kernel computes its cherries)
+            const uint64_t tl = (uint64_t)((d.sl - e->d_states) / e->nptn_pad), tr = (uint64_t)((d.sr - e->d_states) / e->nptn_pad);
+            const uint64_t key = (tl << 32) | tr;
+            auto it = e->cherry_slot_of.find(key);
+            int slot;
+            if (it == e->cherry_slot_of.end()) {
+                if (e->cherry_slots.size() >= e->cherry_cap) continue;
+                slot = (int)e->cherry_slots.size();
+                e->cherry_slots.emplace_back();
+                e->cherry_slot_of[key] = slot;
+            } else {
+                slot = it->second;
+            }
+            iqhip_engine::CherrySlot &cs = e->cherry_slots[slot];
+            const bool same = cs.len_l == d.left_len && cs.len_r == d.right_len;
+            if (cs.stamp == stamp && !same) continue;   // (the same pair with other lengths in one plan: computed the ordinary way)
+            if (!same || cs.model_version != e->model_version) {
+                cs.len_l = d.left_len;
+                cs.len_r = d.right_len;
+                cs.model_version = 0;   // until built (submit_traverse)
+                if (cs.stamp != stamp) e->plan_cherry_jobs.push_back(slot);
+            }
+            cs.stamp = stamp;
+            d.cherry = e->d_cherry_tab + (size_t)slot * per;
+            e->plan_uses_cherry = true;
+        }
+    }
     for (int q = 0; q < kSentinels; q++) dummy_op(e->h_ops[nops + q]);  // targets of the look-ahead requests
     *last_dst = prev_dst;
     // LDS layout of the per-(op, child) regions, cut into chunks that fit the budget
@@ -1303,10 +1426,51 @@ static void timing_end(iqhip_engine *e) {
 }
 
 static double g_dbg_build_us = 0.0;   // IQHIP_DEBUG_SWEEP: host time spent in build_plan
+static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, bool has_root, iqhip_branch_end a,
+                           iqhip_branch_end b, double len, bool skip_reduce = false, const std::vector<int> *explicit_segs = nullptr,
+                           const double *const *len_ptrs = nullptr);
+
+// the tables the current plan needs: one node update per table on the pair engine (independent segments of one
+// submission, same stream), then the move into register order
+static int build_cherry_tables(iqhip_engine *e) {
+    iqhip_engine *p = e->pair;
+    const int n = (int)e->plan_cherry_jobs.size();
+    std::vector<iqhip_node_op> ops((size_t)n);
+    const std::vector<int> segs((size_t)n, 1);
+    for (int i = 0; i < n; i++) {
+        const iqhip_engine::CherrySlot &cs = e->cherry_slots[e->plan_cherry_jobs[i]];
+        iqhip_node_op &o = ops[i];
+        memset(&o, 0, sizeof o);
+        o.dst_key = (uint64_t)e->plan_cherry_jobs[i] + 1;
+        o.left_leaf = 0;
+        o.right_leaf = 1;
+        o.left_len = cs.len_l;
+        o.right_len = cs.len_r;
+    }
+    iqhip_branch_end none = {0, -1, 0};
+    int rc = submit_traverse(p, ops.data(), n, false, none, none, 0.0, /*skip_reduce=*/true, &segs, nullptr);
+    if (rc) return rc;
+    std::vector<const double *> src((size_t)n);
+    std::vector<double *> dst((size_t)n);
+    const size_t per = (size_t)e->cherry_npairs * e->block;
+    for (int i = 0; i < n; i++) {
+        int idx;
+        rc = slab_for_key(p, ops[i].dst_key, false, &idx);
+        if (rc) return rc;
+        src[i] = p->slabs[idx].plh;
+        dst[i] = e->d_cherry_tab + (size_t)e->plan_cherry_jobs[i] * per;
+    }
+    HIPCHK(launch_cherry_transpose(e, src.data(), dst.data(), n, e->cherry_npairs));
+    for (int i = 0; i < n; i++) e->cherry_slots[e->plan_cherry_jobs[i]].model_version = e->model_version;
+    e->cherry_built_total += n;
+    e->plan_cherry_jobs.clear();
+    return IQHIP_OK;
+}
+
 // enqueue: plan upload, K1, fused traversal (+ optional root lnL), fixed-order reduction
 static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, bool has_root,
-                           iqhip_branch_end a, iqhip_branch_end b, double len, bool skip_reduce = false,
-                           const std::vector<int> *explicit_segs = nullptr, const double *const *len_ptrs = nullptr) {
+                           iqhip_branch_end a, iqhip_branch_end b, double len, bool skip_reduce,
+                           const std::vector<int> *explicit_segs, const double *const *len_ptrs) {
     int rc = check_ready(e);
     if (rc) return rc;
     if (nops < 0 || (nops > 0 && !ops)) return fail(IQHIP_ERR_INVALID, "bad ops array");
@@ -1342,6 +1506,12 @@ static int submit_traverse(iqhip_engine *e, const iqhip_node_op *ops, int nops, 
             HIPCHK(launch_leaf_tables(e, reinterpret_cast<const TabJob *>(e->d_ops + e->plan_jobs_off), njobs));
         e->plan_tab_dirty = 0;  // built; the same (cached) plan needs nothing until a length or the model changes
     }
+    if (!e->plan_cherry_jobs.empty()) {
+        rc = build_cherry_tables(e);
+        if (rc) return rc;
+    }
+    if (e->plan_uses_cherry)
+        for (int k = 0; k < nops; k++) e->cherry_ops_total += e->h_ops[k].cherry != nullptr;
     timing_begin(e);
     const int *table = reinterpret_cast<const int *>(e->d_ops + e->plan_table_off);
     {   // the stages of independent subtrees, level by level: one launch each, one set of workgroups per unit
@@ -2474,6 +2644,13 @@ extern "C" int iqhip_optimize_branch_batch(iqhip_engine *e, const iqhip_branch_t
         if (sum_scale)
             for (int k = 0; k < total_ops; k++) sum_scale[k] = e->h_result[2 + k];
     }
+    return IQHIP_OK;
+}
+
+extern "C" int iqhip_debug_cherry_tables(iqhip_engine *e, int64_t *tables_built, int64_t *ops_from_tables) {
+    if (!e) return fail(IQHIP_ERR_INVALID, "null engine");
+    if (tables_built) *tables_built = e->cherry_built_total;
+    if (ops_from_tables) *ops_from_tables = e->cherry_ops_total;
     return IQHIP_OK;
 }
 

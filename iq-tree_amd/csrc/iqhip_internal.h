@@ -65,6 +65,11 @@ struct __attribute__((aligned(16))) DevOp {
     // nullptr: the host value left_len / right_len
     const double *left_len_p;
     const double *right_len_p;
+    // 20 states x 4 categories, both children leaves ("cherry"): the node's whole vector is a function of the pair of leaf
+    // states only -- cherry[(sL * (STATE_UNKNOWN + 1) + sR) * block + ...] holds it for every pair, in the order the lanes
+    // keep it in registers (kernels_mfma.hip k_cherry_transpose); nullptr: compute the three matrix products
+    const double *cherry;
+    const double *_pad_cherry;
 };
 
 #if defined(__HIPCC__)
@@ -293,6 +298,26 @@ struct iqhip_engine {
     std::vector<double> tab_len;          // per slot: branch length the table was built for (NaN: none)
     uint64_t model_version = 1, tab_model_version = 0;
     std::vector<iqhip::TabJob> plan_tab_jobs;  // the current plan's tables: [0, plan_tab_dirty) need (re)building
+    // cherry tables (20 states x 4 categories, DevOp::cherry): slot = pair of taxa; `pair` is a small engine of our own on
+    // the same stream whose pseudo-alignment lists every pair of states -- a cherry's table is that engine's ordinary
+    // node update for the two pendant lengths, moved into register order by k_cherry_transpose
+    struct CherrySlot {
+        double len_l = -1.0, len_r = -1.0;
+        uint64_t model_version = 0;   // model the table was built for (0: never built)
+        uint64_t stamp = 0;           // last plan that used the slot
+    };
+    bool cherry_on = true;                 // IQHIP_CHERRY_TABLES=0 switches the tables off
+    iqhip_engine *pair = nullptr;
+    int cherry_s2 = 0, cherry_npairs = 0;  // STATE_UNKNOWN + 1; its square padded to whole 64-pattern groups
+    double *d_cherry_tab = nullptr;
+    size_t cherry_cap = 0;                 // slots allocated
+    std::unordered_map<uint64_t, int> cherry_slot_of;   // (taxon_l << 32 | taxon_r) -> slot
+    std::vector<CherrySlot> cherry_slots;
+    std::vector<int> plan_cherry_jobs;     // slots the current plan needs (re)built before its traversal
+    uint64_t cherry_stamp = 0, plan_cherry_model = 0;   // (model version the current plan's tables were scheduled for)
+    bool plan_uses_cherry = false;
+    int64_t cherry_built_total = 0, cherry_ops_total = 0;   // tables built / node updates answered from a table so far
+    bool cherry_model_synced = false;      // the pair engine has the model of this engine's last set_model call
     int plan_tab_dirty = 0;
     int plan_jobs_off = 0;                // DevOp index where the device copy of the job list starts
     int plan_nleaf_tabs = 0;              // tables the current plan uses (0: kernel variant without tables)
@@ -671,6 +696,8 @@ void newton_task_fill(void *dst, const DevBranch &br, double xguess, double x1, 
 // kernels_mfma.hip (nstates 20 / 64)
 hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs, int nwaves, bool top_stage = false);
 hipError_t launch_leaf_tables(iqhip_engine *e, const TabJob *d_jobs, int njobs);
+// cherry tables: src[i] (tile layout, npairs patterns) -> dst[i] (register order of the traversal kernel), host pointer arrays
+hipError_t launch_cherry_transpose(iqhip_engine *e, const double *const *src, double *const *dst, int n, int npairs);
 size_t leaf_table_doubles(const iqhip_engine *e);          // doubles per (leaf child) table: ncat * state_unknown * n
 int mfma2_fixed_lds_doubles(int n);
 // mode 0: branch lnL, 1: theta, 2: df/ddf from theta, 3: lnL from theta

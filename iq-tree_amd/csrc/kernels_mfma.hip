@@ -432,6 +432,43 @@ hipError_t launch_leaf_tables(iqhip_engine *e, const TabJob *d_jobs, int njobs) 
     return hipGetLastError();
 }
 
+// Cherry tables (20 states): a node whose two children are leaves has one of (STATE_UNKNOWN + 1)^2 vectors per pattern.
+// The engine computes them once per (pair of taxa, pendant lengths, model) by running the ordinary node update on a
+// pseudo-alignment that lists every pair of states (iqhip_engine::pair: same kernels, same bits), and this kernel moves
+// the result out of the tile layout [tile][c][row][16] into the order in which a lane of the traversal kernel holds
+// an op's result: entry q = 40 double2, piece j * 4 + g = values (2j, 2j + 1) of lane group g, value s = 5 c + r,
+// r < 4: row 4 r + g of the 16-row tile, r = 4: tail row 16 + g.
+struct CherryMoves {
+    const double *src[32];
+    double *dst[32];
+    int n;
+};
+__global__ __launch_bounds__(256) void k_cherry_transpose(const CherryMoves M, int npairs, int block) {
+    const double *src = M.src[blockIdx.y];
+    double *dst = M.dst[blockIdx.y];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= npairs * block) return;
+    const int q = t / block, idx = t - q * block;
+    const int j = idx >> 3, g = (idx >> 1) & 3, hbit = idx & 1;
+    const int s = 2 * j + hbit, c = s / 5, r = s - 5 * c;
+    const int row = r < 4 ? 4 * r + g : 16 + g;
+    dst[t] = src[((size_t)(q >> 4) * block + c * 20 + row) * 16 + (q & 15)];
+}
+
+hipError_t launch_cherry_transpose(iqhip_engine *e, const double *const *src, double *const *dst, int n, int npairs) {
+    for (int first = 0; first < n; first += 32) {
+        CherryMoves M;
+        M.n = std::min(32, n - first);
+        for (int i = 0; i < 32; i++) {
+            M.src[i] = src[first + (i < M.n ? i : 0)];
+            M.dst[i] = dst[first + (i < M.n ? i : 0)];
+        }
+        hipLaunchKernelGGL(k_cherry_transpose, dim3((unsigned)((npairs * e->block + 255) / 256), (unsigned)M.n), dim3(256), 0,
+                           e->stream, M, npairs, e->block);
+    }
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------
 // Pipelined variant (compile-time category count).  Differences from k_traverse_mfma:
 //   * the previous op's result stays in registers: its accumulator image IS the B operand of
@@ -454,6 +491,7 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
     // memory the rows cost more than the matrix products they replace once result stores are in flight (r02: 1.07 vs
     // 1.03 ms; even without any other traffic 0.78 vs 0.89 ms where the products removed are 34 % of the matrix work)
     constexpr bool TABL = TAB && (N < 64);
+    constexpr bool CHERRY = (N == 20) && !TAB && (C % 2 == 0) && (CS == 1);   // (the two-waves-per-tile form has no registers to spare)
     // rows of U / U^-1: MTF full 16-row tiles on v_mfma_f64_16x16x4_f64 plus, for N = 20, the four
     // left-over rows on v_mfma_f64_4x4x4_4b_f64 (4 blocks = the tile's 4 groups of 4 patterns).
     // Lane layouts of the 4x4x4 form (measured, tools/mfma444_probe.hip): A[i][k] at lane
@@ -602,6 +640,10 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
             sRn = nxop.sr[ptn];
             const bool holdL = HOLDS && op.left_kind == CHILD_HOLD;
             const bool push = HOLDS && op.push_hold;
+            // CHERRY: both children are leaves and the engine holds the node's vector for every pair of leaf states (L2 /
+            // Infinity-Cache resident table, DevOp::cherry): this lane's 5 * C values arrive as 16-byte pieces and no
+            // matrix instruction is issued for the op
+            const double *const cherry = CHERRY ? op.cherry : nullptr;
             if (!leafL) sc += holdL ? hold_sc : pfn_sc;                 // pfn_sc / hold_sc: valid on g == 0 lanes
             // scalar fields of the op that are needed only in its tail: requested now
             int16_t *const dst_sc = op.dst_sc;
@@ -633,6 +675,62 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
             const double *rowR = (TABL ? sReg + op.lds_right : op.tabR) + (size_t)(sR < S ? sR : 0) * N + 4 * g;
             double *dst = op.dst + tbase;
             unsigned lmax = 0;
+            bool from_table = false;
+            if constexpr (CHERRY) {
+                if (cherry) {
+                    // a category's result: kept as the next op's `prev`, stored, parked if a later op of the launch wants it
+                    auto finish_cat = [&](int c, const v4f64 (&O)[MTF], double o4) {
+        #pragma unroll
+                        for (int m = 0; m < MTF; m++) {
+                            prev[c][m] = O[m];
+        #pragma unroll
+                            for (int r = 0; r < 4; r++) {
+                                const int row = 16 * m + 4 * r + g;
+        #ifndef IQHIP_MFMA_ABLATE_NOSTORE  // timing-only build switch; never defined in the shipped library
+                                // (streaming hint: most results are not read again before they leave the L2; protein -1 %, codon -2 %)
+                                __builtin_nontemporal_store(O[m][r], &dst[(size_t)((coff + c) * N + row) * 16 + p]);
+        #endif
+                                if (HOLDS && push) hold[((coff + c) * N + 16 * m + 4 * r) * 16] = O[m][r];
+                                lmax = amax_hi(lmax, O[m][r]);
+                            }
+                        }
+                        if (TAIL4) {
+                            prevT[c] = o4;
+        #ifndef IQHIP_MFMA_ABLATE_NOSTORE
+                            __builtin_nontemporal_store(o4, &dst[(size_t)((coff + c) * N + 16 * MTF + g) * 16 + p]);
+        #endif
+                            if (HOLDS && push) hold[((coff + c) * N + 16 * MTF) * 16] = o4;
+                            lmax = amax_hi(lmax, o4);
+                        }
+                    };
+                    // (the streamed child of the next op's first category, as the last category step of any op requests it)
+#ifdef IQHIP_MFMA_ABLATE_NOLOAD
+                    const bool nreal = false;
+#else
+                    const bool nreal = nxop.real_mask & 1;
+#endif
+                    const double *nsrc = nxop.pf + (nreal ? tbase + (size_t)coff * N * 16 : 0);
+#pragma unroll
+                    for (int s = 0; s < KS; s++) PFn[s] = nsrc[s * 64 + lane];
+                    if (g == 0) pfn_sc = nxop.pf_sc[nreal ? ptn : (int64_t)p];
+                    const double2 *src = reinterpret_cast<const double2 *>(cherry + (size_t)(sL * (A.state_unknown + 1) + sR) * B) +
+                                         (coff * 5 / 2) * 4 + g;
+                    double2 CTv[5 * C / 2];   // values (2j, 2j + 1) of this lane; value 5 c + r: category c, register r
+#pragma unroll
+                    for (int j = 0; j < 5 * C / 2; j++) CTv[j] = src[j * 4];
+                    auto val = [&](int s) { return (s & 1) ? CTv[s >> 1].y : CTv[s >> 1].x; };
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        TRACE_STAMP();
+                        v4f64 O[MTF];
+                        O[0] = (v4f64){val(5 * c), val(5 * c + 1), val(5 * c + 2), val(5 * c + 3)};
+                        finish_cat(c, O, val(5 * c + 4));
+                        TRACE_STAMP();
+                    }
+                    from_table = true;
+                }
+            }
+            if (!from_table) {
 #pragma unroll
             for (int c = 0; c < C; c++) {
                 // streamed child of the next step: (k, c+1) or (k+1, 0); its k-step slices replace the
@@ -838,6 +936,7 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
                 }
                 TRACE_STAMP();   // contraction done, stores issued
             }
+            }   // (!from_table)
             if (no_scale == 2 && lmax == 0) {   // scalar rule: exactly zero, or only below 2^-1042?
                 unsigned nz = 0;
 #pragma unroll
