@@ -619,14 +619,16 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
 // ---------------------------------------------------------------------------------------
 static bool cherry_candidate(const iqhip_engine *e) {
     if (!e || !e->cherry_on || e->planner || !e->shards.empty() || e->ablate) return false;
-    if (!(e->mfma_pipelined_ok && e->n == 20 && e->n_user == 20 && e->ncat == 4) || e->leaf_tables || e->cat_split) return false;
-    return e->nptn_pad >= 8 * 1024;   // (a table costs one node update over <= 1024 patterns per new pair of lengths)
+    if (!e->mfma_pipelined_ok || e->n_user != e->n) return false;
+    if (e->n == 20) return e->ncat == 4 && !e->leaf_tables && !e->cat_split && e->nptn_pad >= 8 * 1024;
+    return false;
 }
 
 static int cherry_sync_model(iqhip_engine *e, const double *eval, const double *evec, const double *inv_evec,
                              const double *rates, const double *props, int state_unknown, const double *tip) {
     const int s2 = state_unknown + 1;
-    if (s2 * s2 > 1024) {   // (too many pairs of states: no tables)
+    // a table costs one node update over s2^2 patterns per new pair of pendant lengths, and 8 * block * s2^2 bytes
+    if (s2 * s2 > 4356 || (int64_t)4 * s2 * s2 > e->nptn_pad) {
         if (e->pair) iqhip_destroy(e->pair);
         e->pair = nullptr;
         return IQHIP_OK;
@@ -639,7 +641,7 @@ static int cherry_sync_model(iqhip_engine *e, const double *eval, const double *
     int rc = IQHIP_OK;
     if (!e->pair) {
         const int npairs = s2 * s2;
-        rc = iqhip_create(&e->pair, e->device, 20, e->ncat, npairs, 2);
+        rc = iqhip_create(&e->pair, e->device, e->n, e->ncat, npairs, 2);
         if (rc) return rc;
         e->pair->cherry_on = false;
         e->pair->check_plans = e->check_plans;
@@ -1247,7 +1249,8 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
         for (int k = 0; k < nops; k++) {
             DevOp &d = e->h_ops[k];
             if (d.left_kind != CHILD_LEAF || d.right_kind != CHILD_LEAF || d.left_len_p || d.right_len_p) continue;
-            if (e->top_cs2 && seg_of[k] == 0) continue;   // (the top stage's two-waves-per-tile kernel computes its cherries)
+            // (the top stage's two-waves-per-tile / row-split kernels compute their cherries)
+            if ((e->top_cs2 || (e->n == 64 && e->mixed_top)) && seg_of[k] == 0) continue;
             const uint64_t tl = (uint64_t)((d.sl - e->d_states) / e->nptn_pad), tr = (uint64_t)((d.sr - e->d_states) / e->nptn_pad);
             const uint64_t key = (tl << 32) | tr;
             auto it = e->cherry_slot_of.find(key);

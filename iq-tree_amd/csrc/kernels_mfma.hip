@@ -436,23 +436,24 @@ hipError_t launch_leaf_tables(iqhip_engine *e, const TabJob *d_jobs, int njobs) 
 // The engine computes them once per (pair of taxa, pendant lengths, model) by running the ordinary node update on a
 // pseudo-alignment that lists every pair of states (iqhip_engine::pair: same kernels, same bits), and this kernel moves
 // the result out of the tile layout [tile][c][row][16] into the order in which a lane of the traversal kernel holds
-// an op's result: entry q = 40 double2, piece j * 4 + g = values (2j, 2j + 1) of lane group g, value s = 5 c + r,
-// r < 4: row 4 r + g of the 16-row tile, r = 4: tail row 16 + g.
+// an op's result: entry q = block / 2 double2, piece j * 4 + g = values (2j, 2j + 1) of lane group g, value s = VPL c + v
+// (VPL = 4 n/16 + tail values per category and lane), v < 4 n/16: row 16 (v / 4) + 4 (v % 4) + g, else tail row 16 (n/16) + g.
 struct CherryMoves {
     const double *src[32];
     double *dst[32];
     int n;
 };
-__global__ __launch_bounds__(256) void k_cherry_transpose(const CherryMoves M, int npairs, int block) {
+__global__ __launch_bounds__(256) void k_cherry_transpose(const CherryMoves M, int npairs, int block, int n) {
     const double *src = M.src[blockIdx.y];
     double *dst = M.dst[blockIdx.y];
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= npairs * block) return;
     const int q = t / block, idx = t - q * block;
     const int j = idx >> 3, g = (idx >> 1) & 3, hbit = idx & 1;
-    const int s = 2 * j + hbit, c = s / 5, r = s - 5 * c;
-    const int row = r < 4 ? 4 * r + g : 16 + g;
-    dst[t] = src[((size_t)(q >> 4) * block + c * 20 + row) * 16 + (q & 15)];
+    const int mtf = n / 16, vpl = 4 * mtf + ((n % 16) == 4 ? 1 : 0);
+    const int s = 2 * j + hbit, c = s / vpl, v = s - vpl * c;
+    const int row = v < 4 * mtf ? 16 * (v >> 2) + 4 * (v & 3) + g : 16 * mtf + g;
+    dst[t] = src[((size_t)(q >> 4) * block + c * n + row) * 16 + (q & 15)];
 }
 
 hipError_t launch_cherry_transpose(iqhip_engine *e, const double *const *src, double *const *dst, int n, int npairs) {
@@ -464,7 +465,7 @@ hipError_t launch_cherry_transpose(iqhip_engine *e, const double *const *src, do
             M.dst[i] = dst[first + (i < M.n ? i : 0)];
         }
         hipLaunchKernelGGL(k_cherry_transpose, dim3((unsigned)((npairs * e->block + 255) / 256), (unsigned)M.n), dim3(256), 0,
-                           e->stream, M, npairs, e->block);
+                           e->stream, M, npairs, e->block, e->n);
     }
     return hipGetLastError();
 }
@@ -484,14 +485,20 @@ hipError_t launch_cherry_transpose(iqhip_engine *e, const double *const *src, do
 // small alignment yields CS times the waves with 1/CS of the dependent MFMA chain per op; the only cross-wave step is
 // the scaling maximum of a pattern (LDS + one workgroup barrier per op).
 // TAB: LEAF children are table look-ups (k_leaf_tables) instead of U * (ex .* tip) products on the matrix pipe.
+// tile0: first tile of this role (mixed-role top stages)
 template <int N, int C, int WG, int CS, bool TAB>
-__device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vblock) {
+__device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vblock, const int64_t tile0 = 0) {
     // TABL (20 states): the K2 tables of the chunk's LEAF children are copied into LDS when the chunk is filled (the four
     // waves of a workgroup walk the same ops) and a lane reads its pattern's row with ds_read_b128: gathered from global
     // memory the rows cost more than the matrix products they replace once result stores are in flight (r02: 1.07 vs
     // 1.03 ms; even without any other traffic 0.78 vs 0.89 ms where the products removed are 34 % of the matrix work)
     constexpr bool TABL = TAB && (N < 64);
-    constexpr bool CHERRY = (N == 20) && !TAB && (C % 2 == 0) && (CS == 1);   // (the two-waves-per-tile form has no registers to spare)
+    // values of one category that a lane holds of an op's result (4 per 16-row tile + the tail row), see k_cherry_transpose
+    constexpr int VPL = 4 * (N / 16) + ((N % 16) == 4 ? 1 : 0);
+    // (20 states only.  Measured for 64 states, 50 x 20k codons: the extra block costs that kernel 39 spilled registers --
+    // 0.400 ms without tables, 0.346 with, against 0.326 before the block existed; the two-waves-per-tile form of 20 states
+    // has no registers to spare either)
+    constexpr bool CHERRY = (N == 20) && ((C * VPL) % 2 == 0) && (CS == 1);
     // rows of U / U^-1: MTF full 16-row tiles on v_mfma_f64_16x16x4_f64 plus, for N = 20, the four
     // left-over rows on v_mfma_f64_4x4x4_4b_f64 (4 blocks = the tile's 4 groups of 4 patterns).
     // Lane layouts of the 4x4x4 form (measured, tools/mfma444_probe.hip): A[i][k] at lane
@@ -543,7 +550,7 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
     const CONST_AS char *kargs = (const CONST_AS char *)__builtin_amdgcn_kernarg_segment_ptr();
     const CONST_AS int *segs = A.small_plan ? (const CONST_AS int *)(kargs + offsetof(TravMArgs, small_segs)) : as_const(A.segs);
     const int k_begin = segs[2 * seg], k_end = k_begin + segs[2 * seg + 1];
-    const int64_t tile = (int64_t)(vblock - seg * A.ngroups) * (WPB / CS) + wave / CS;
+    const int64_t tile = tile0 + (int64_t)(vblock - seg * A.ngroups) * (WPB / CS) + wave / CS;
     const int coff = (wave % CS) * C;          // first category of this wave
     const bool lead = (wave % CS) == 0;        // the wave that owns the tile's counters and sums
     const bool active = tile < A.ntiles;
@@ -714,18 +721,22 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
                     for (int s = 0; s < KS; s++) PFn[s] = nsrc[s * 64 + lane];
                     if (g == 0) pfn_sc = nxop.pf_sc[nreal ? ptn : (int64_t)p];
                     const double2 *src = reinterpret_cast<const double2 *>(cherry + (size_t)(sL * (A.state_unknown + 1) + sR) * B) +
-                                         (coff * 5 / 2) * 4 + g;
-                    double2 CTv[5 * C / 2];   // values (2j, 2j + 1) of this lane; value 5 c + r: category c, register r
+                                         (coff * VPL / 2) * 4 + g;
+                    {
+                        double2 CTv[VPL * C / 2];   // values (2j, 2j + 1) of this lane; value VPL c + v: category c, register v
 #pragma unroll
-                    for (int j = 0; j < 5 * C / 2; j++) CTv[j] = src[j * 4];
-                    auto val = [&](int s) { return (s & 1) ? CTv[s >> 1].y : CTv[s >> 1].x; };
+                        for (int j = 0; j < VPL * C / 2; j++) CTv[j] = src[j * 4];
+                        auto val = [&](int s) { return (s & 1) ? CTv[s >> 1].y : CTv[s >> 1].x; };
 #pragma unroll
-                    for (int c = 0; c < C; c++) {
-                        TRACE_STAMP();
-                        v4f64 O[MTF];
-                        O[0] = (v4f64){val(5 * c), val(5 * c + 1), val(5 * c + 2), val(5 * c + 3)};
-                        finish_cat(c, O, val(5 * c + 4));
-                        TRACE_STAMP();
+                        for (int c = 0; c < C; c++) {
+                            TRACE_STAMP();
+                            v4f64 O[MTF];
+#pragma unroll
+                            for (int m = 0; m < MTF; m++)
+                                O[m] = (v4f64){val(VPL * c + 4 * m), val(VPL * c + 4 * m + 1), val(VPL * c + 4 * m + 2), val(VPL * c + 4 * m + 3)};
+                            finish_cat(c, O, TAIL4 ? val(VPL * c + (TAIL4 ? 4 * MTF : 0)) : 0.0);
+                            TRACE_STAMP();
+                        }
                     }
                     from_table = true;
                 }
@@ -1009,6 +1020,15 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
 template <int N, int C, int WG, int CS = 1, bool TAB = false>
 __global__ __launch_bounds__(WG, (N == 20 && C == 2 && CS == 2) ? 3 : 2) void k_traverse_mfma2(const TravMArgs A) {
     trav_mfma2_body<N, C, WG, CS, TAB>(A, (int)blockIdx.x);
+}
+
+// The mixed-role top stage of 20 states x 4 categories: the two-waves-per-tile form fills whole rounds of the chip (3
+// workgroups per CU x 2 tiles); the few tiles beyond the last whole round -- 53 of 3125 at 50 000 patterns, which used to
+// cost a third round of a nearly empty chip -- run as one wave per category (half the chain per wave) in workgroups that
+// are dispatched first.  Same per-pattern arithmetic in both roles: same bits.
+__global__ __launch_bounds__(256, 3) void k_traverse_mfma_top20(const TravMArgs F, const int nrest, const TravMArgs R, const int64_t tile0R) {
+    if ((int)blockIdx.x < nrest) trav_mfma2_body<20, 1, 256, 4, false>(R, (int)blockIdx.x, tile0R);
+    else trav_mfma2_body<20, 2, 256, 2, false>(F, (int)blockIdx.x - nrest);
 }
 
 template <int N, bool MIX>
@@ -1455,6 +1475,31 @@ static hipError_t launch_trav_m2(iqhip_engine *e, TravMArgs &A) {
     return hipGetLastError();
 }
 
+static hipError_t launch_trav_top20(iqhip_engine *e, TravMArgs &A, int nfull_wg) {
+    const int nx = e->state_unknown + 1 - 20;
+    const size_t lds = (size_t)(mfma2_fixed_lds_doubles(20) + nx * 20 + e->plan_lds_doubles) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma_top20), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    A.hold_off = -1;
+    if (e->plan_small && A.nsegs_launch == 1) {
+        A.small_plan = 1;
+        A.small_segs[0] = 0;
+        A.small_segs[1] = e->plan_small_nops;
+        for (int q = 0; q < kSmallPlanOps; q++) A.small_ops[q] = e->h_ops[q];
+    }
+    TravMArgs F = A, R = A;
+    F.ntiles = (int64_t)nfull_wg * 2;
+    F.ngroups = nfull_wg;
+    const int nrest = (int)(A.ntiles - F.ntiles);
+    R.ngroups = nrest;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_traverse_mfma_top20, dim3((unsigned)(nrest + nfull_wg)), dim3(256), lds, e->stream, F, nrest, R, F.ntiles);
+    return hipGetLastError();
+}
+
 // the mixed-role top stage (k_traverse_mfma_top64): full-chain workgroups for whole rounds of the chip, row-split
 // workgroups for the tiles that are left over
 template <bool TAB>
@@ -1574,7 +1619,14 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs
         }
         if (e->n == 20 && e->ncat == 4) {
             if (e->cat_split) return launch_trav_m2<20, 1, 4>(e, A);
-            if (e->top_cs2 && top_stage) return launch_trav_m2<20, 2, 2>(e, A);
+            if (e->top_cs2 && top_stage) {
+                // whole rounds of two-waves-per-tile workgroups; a small remainder as one wave per category (launch_trav_top20)
+                const int64_t per_round = (int64_t)e->num_cus * 3 * 2;
+                const int64_t rounds = e->ntiles / per_round, rest = e->ntiles - rounds * per_round;
+                if (e->mixed_top && nsegs == 1 && rounds >= 1 && rest > 0 && rest <= per_round / 4)
+                    return launch_trav_top20(e, A, (int)(rounds * e->num_cus * 3));
+                return launch_trav_m2<20, 2, 2>(e, A);
+            }
             return launch_trav_m2<20, 4>(e, A);
         }
         if (e->n == 20 && e->ncat == 1) return launch_trav_m2<20, 1>(e, A);
