@@ -73,6 +73,33 @@ struct __attribute__((aligned(16))) DevOp {
 };
 
 #if defined(__HIPCC__)
+// Sum over the 64 lanes of a wave, every lane gets it: the xor butterfly v += v^32, ^16, ^8, ^4, ^2, ^1 of the shuffle
+// form, on the vector ALU instead of six dependent ds_bpermute round trips through the LDS crossbar (a derivative
+// evaluation of a branch-length sweep spent half its 2 us in two of these).  Same bits as the shuffle form: the permlane
+// swaps and quad permutes deliver exactly lane^32, ^16, ^2, ^1; row_ror:8 is lane^8 within a 16-lane row; row_ror:4
+// delivers lane (i + 4) mod 16 instead of i^4, which holds the same value, because after the ^8 step lanes that agree in
+// their low three bits hold equal sums -- and fp addition commutes.
+__device__ __forceinline__ double wave_sum64(double v) {
+    unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    lo = __double2loint(v);
+    hi = __double2hiint(v);
+    auto c = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto d = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
+#define IQHIP_DPP_STEP(ctrl)                                                                                  \
+    v += __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xF, 0xF, true),                  \
+                          __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xF, 0xF, true));
+    IQHIP_DPP_STEP(0x128)   // row_ror:8
+    IQHIP_DPP_STEP(0x124)   // row_ror:4
+    IQHIP_DPP_STEP(0x4E)    // quad_perm [2,3,0,1]
+    IQHIP_DPP_STEP(0xB1)    // quad_perm [1,0,3,2]
+#undef IQHIP_DPP_STEP
+    return v;
+}
+
 // length of a child branch of a node update: the host value, or the result of an earlier step of a sweep
 template <typename OpRef>
 __device__ __forceinline__ double op_child_len(const OpRef &d, int child) {

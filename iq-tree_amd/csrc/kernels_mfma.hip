@@ -156,11 +156,7 @@ __device__ __forceinline__ unsigned group_max_u(unsigned v) {
     return b[0] > b[1] ? b[0] : b[1];
 }
 
-__device__ __forceinline__ double wave_sum_m(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum_m(double v) { return wave_sum64(v); }
 
 struct TravMArgs {
     const DevOp *ops;

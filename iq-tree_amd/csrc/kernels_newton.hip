@@ -113,11 +113,7 @@ __device__ __forceinline__ double group_sum(double v) {
     return __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
 }
 
-__device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ double wsum(double v) { return wave_sum64(v); }
 
 // sum over this workgroup's patterns of f*df_ptn and f*ddf_ptn at the val arrays in LDS
 // MODE 0: derivative sums (f*df_ptn, f*ddf_ptn); MODE 1: lnL sum (f*log|lh_ptn|) in odf.  The workgroup is

@@ -27,11 +27,7 @@ __device__ __forceinline__ const CONST_AS T *sw_const(const T *p) {
     return (const CONST_AS T *)(p);
 }
 
-__device__ __forceinline__ double sw_wsum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ double sw_wsum(double v) { return wave_sum64(v); }
 
 struct SweepArgs {
     const SweepOp *ops;
@@ -50,6 +46,7 @@ struct SweepArgs {
     int max_steps;
     double *posts;      // [2 step parities][kNewtonPostEpochs][grid][2], all-ones = not posted yet
     double *out;        // [nsteps][6] = {optx, d2l, evaluations, status, diverged, -}
+    unsigned long long *prof;   // IQHIP_DEBUG_SWEEP: [8] ticks of the 100 MHz clock spent in {node updates, theta, evaluations, step tail} + counts
 };
 
 // one node update of one 64-pattern tile, lane = pattern: the arithmetic of node_update4 / leaf_cat4 (kernels_valu4.hip)
@@ -161,10 +158,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_sweep4(const SweepArgs A) {
     double *s_tip = smem;               // [32][4]
     double *s_ex = s_tip + 128;         // [2][B]
     double *s_tab = s_ex + 2 * B;       // [2][5B]
-    double *s_v0 = s_tab + 10 * B, *s_v1 = s_v0 + B, *s_v2 = s_v1 + B;
-    double *s_red = s_v2 + B;           // [2 * WAVES]
-    double *s_bcast = s_red + 16;       // [2]
-    double *s_len = s_bcast + 2;        // [nsteps] accepted lengths of the steps so far
+    double *s_red = s_tab + 10 * B;     // [2 parities][2 * WAVES]
+    double *s_bcast = s_red + 32;       // [2 parities][2]
+    // launch constants, read from memory once (every step of the sweep used to start with a round trip for them)
+    double *s_cof = s_bcast + 4;        // [B] evalc[c][i] * rates[c]
+    double *s_prop = s_cof + B;         // [B] props[c]
+    double *s_eval = s_prop + B;        // [4]
+    double *s_rate = s_eval + 4;        // [C]
+    double *s_evec = s_rate + C;        // [16]
+    double *s_vw = s_evec + 16;         // [WAVES][3 B] exp / derivative factors of an evaluation, one copy per wave
+    double *s_len = s_vw + WAVES * 3 * B;   // [nsteps] accepted lengths of the steps so far
     __shared__ int s_fail;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int G = (int)gridDim.x, wg = (int)blockIdx.x;
@@ -174,11 +177,28 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_sweep4(const SweepArgs A) {
     const CONST_AS SweepOp *ops = sw_const(A.ops);
     const CONST_AS SweepStep *steps = sw_const(A.steps);
     for (int t = threadIdx.x; t < (A.state_unknown + 1) * 4; t += NT) s_tip[t] = A.tip[t];
+    for (int t = threadIdx.x; t < B; t += NT) {
+        s_cof[t] = A.evalc[t] * A.rates[t >> 2];
+        s_prop[t] = A.props[t >> 2];
+        s_evec[t & 15] = A.evec[t & 15];
+        if (t < 4) s_eval[t] = A.eval[t];
+        if (t < C) s_rate[t] = A.rates[t];
+    }
+    if (B < 16) for (int t = threadIdx.x; t < 16; t += NT) s_evec[t] = A.evec[t];
     if (threadIdx.x == 0) s_fail = 0;
+    // REG: the wave's one tile -- its pattern's frequency and invariant-site term stay in registers
+    const int64_t my_ptn = (int64_t)gw * 64 + lane;
+    const bool my_in = REG && gw < A.ntiles && my_ptn < A.nptn;
+    const double my_freq = my_in ? A.freq[my_ptn] : 0.0, my_invar = my_in ? A.invar[my_ptn] : 0.0;
+    unsigned int evals = 0;   // evaluations so far: parity of the reduction buffers
+    __syncthreads();
     const size_t per_parity = (size_t)kNewtonPostEpochs * G * 2;
 
+    const bool prof = A.prof != nullptr && wg == 0 && threadIdx.x == 0;
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int j = 0; j < A.nsteps; j++) {
         const CONST_AS SweepStep &st = steps[j];
+        unsigned long long tk0 = prof ? wall_clock64() : 0;
         unsigned long long *posts = reinterpret_cast<unsigned long long *>(A.posts) + (size_t)(j & 1) * per_parity;
         unsigned long long *posts_other = reinterpret_cast<unsigned long long *>(A.posts) + (size_t)((j + 1) & 1) * per_parity;
         unsigned int epoch = 0;
@@ -191,7 +211,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_sweep4(const SweepArgs A) {
                 const int childi = t / B, e = t - childi * B;
                 const int from = childi ? op.rlen_step : op.llen_step;
                 const double len = from >= 0 ? s_len[from] : (childi ? op.rlen : op.llen);
-                s_ex[t] = exp(A.eval[e & 3] * (A.rates[e >> 2] * len));
+                s_ex[t] = exp(s_eval[e & 3] * (s_rate[e >> 2] * len));
             }
             __syncthreads();
             for (int t = threadIdx.x; t < 2 * 5 * B; t += NT) {   // K2 tables of leaf children, the reference's association
@@ -201,10 +221,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_sweep4(const SweepArgs A) {
                 const double *ex = s_ex + childi * B;
                 double v = 1.0;
                 if (row < 4) {
-                    const double e0 = __dmul_rn(A.evec[x * 4 + 0], ex[c * 4 + 0]);
-                    const double e1 = __dmul_rn(A.evec[x * 4 + 1], ex[c * 4 + 1]);
-                    const double e2 = __dmul_rn(A.evec[x * 4 + 2], ex[c * 4 + 2]);
-                    const double e3 = __dmul_rn(A.evec[x * 4 + 3], ex[c * 4 + 3]);
+                    const double e0 = __dmul_rn(s_evec[x * 4 + 0], ex[c * 4 + 0]);
+                    const double e1 = __dmul_rn(s_evec[x * 4 + 1], ex[c * 4 + 1]);
+                    const double e2 = __dmul_rn(s_evec[x * 4 + 2], ex[c * 4 + 2]);
+                    const double e3 = __dmul_rn(s_evec[x * 4 + 3], ex[c * 4 + 3]);
                     const double *tp = s_tip + row * 4;
                     v = __dadd_rn(__dadd_rn(__dmul_rn(e0, tp[0]), __dmul_rn(e1, tp[1])),
                                   __dadd_rn(__dmul_rn(e2, tp[2]), __dmul_rn(e3, tp[3])));
@@ -219,6 +239,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_sweep4(const SweepArgs A) {
             if (lane == 0) A.slab[(size_t)op.row * A.nwaves + gw] = ws;
         }
 
+        unsigned long long tk1 = prof ? wall_clock64() : 0;
         // ---- theta = a .* b of the branch (phylokernel.h:535-573), kept in registers when the wave has one tile
         double th[REG ? B : 1];
         const bool have_tile = gw < A.ntiles;
@@ -243,16 +264,21 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_sweep4(const SweepArgs A) {
         // sums over all patterns of {f*df_ptn, f*ddf_ptn} (MODE 0) or f*log|lh_ptn| (MODE 1) at branch length x,
         // exchanged between the workgroups in k_newton's posted form and fixed order
         auto eval_at = [&](double x, int mode, double &r0, double &r1) {
-            __syncthreads();
-            for (int t = threadIdx.x; t < B; t += NT) {
-                const int c = t >> 2;
-                const double cof = A.evalc[t] * A.rates[c];
-                const double v = exp(cof * x) * A.props[c];
-                s_v0[t] = v;
-                s_v1[t] = cof * v;
-                s_v2[t] = cof * (cof * v);
+            // every wave makes its own copy of the B factors (lanes < B): no workgroup barrier before the sums
+            double *s_v0 = s_vw + wave * 3 * B, *s_v1 = s_v0 + B, *s_v2 = s_v1 + B;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < B) {
+                const double cof = s_cof[lane];
+                const double v = exp(cof * x) * s_prop[lane];
+                s_v0[lane] = v;
+                s_v1[lane] = cof * v;
+                s_v2[lane] = cof * (cof * v);
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double *red = s_red + (evals & 1u) * 16, *bcast = s_bcast + (evals & 1u) * 2;
+            evals++;
             double adf = 0.0, addf = 0.0;
             for (int64_t tile = gw; tile < A.ntiles; tile += (int64_t)G * WAVES) {
                 const int64_t ptn = tile * 64 + lane;
@@ -268,8 +294,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_sweep4(const SweepArgs A) {
                     d2 = fma(s_v2[2 * jj], t.x, d2); d2 = fma(s_v2[2 * jj + 1], t.y, d2);
                 }
                 if (ptn < A.nptn) {
-                    lh += A.invar[ptn];
-                    const double f = A.freq[ptn];
+                    lh += REG ? my_invar : A.invar[ptn];
+                    const double f = REG ? my_freq : A.freq[ptn];
                     if (mode == 1) {
                         double l = log(fabs(lh));
                         if (isnan(l) || isinf(l)) l = kLogScalingThreshold * 4;  // the reference's repair, phylokernel.h:1100-1122
@@ -286,15 +312,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_sweep4(const SweepArgs A) {
             (void)have_tile;
             adf = sw_wsum(adf);
             addf = sw_wsum(addf);
-            if (lane == 0) { s_red[2 * wave] = adf; s_red[2 * wave + 1] = addf; }
+            // (two buffers, by the evaluation's parity: the waves that are still reading this one cannot be overtaken by a
+            // write of the evaluation after the next, which lies behind the next evaluation's barrier)
+            if (lane == 0) { red[2 * wave] = adf; red[2 * wave + 1] = addf; }
             __syncthreads();
-            double p0 = (s_red[0] + s_red[2]) + (s_red[4] + s_red[6]);
-            double p1 = (s_red[1] + s_red[3]) + (s_red[5] + s_red[7]);
+            double p0 = (red[0] + red[2]) + (red[4] + red[6]);
+            double p1 = (red[1] + red[3]) + (red[5] + red[7]);
             if (WAVES == 8) {
-                p0 += (s_red[8] + s_red[10]) + (s_red[12] + s_red[14]);
-                p1 += (s_red[9] + s_red[11]) + (s_red[13] + s_red[15]);
+                p0 += (red[8] + red[10]) + (red[12] + red[14]);
+                p1 += (red[9] + red[11]) + (red[13] + red[15]);
             }
-            __syncthreads();
             if (G > 1) {
                 unsigned long long *slots = posts + (size_t)epoch * G * 2;
                 if (threadIdx.x == 0) {
@@ -323,12 +350,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_sweep4(const SweepArgs A) {
                     }
                     a = sw_wsum(a);
                     b = sw_wsum(b);
-                    if (threadIdx.x == 0) { s_bcast[0] = a; s_bcast[1] = b; }
+                    if (threadIdx.x == 0) { bcast[0] = a; bcast[1] = b; }
                 }
                 __syncthreads();
-                p0 = s_bcast[0];
-                p1 = s_bcast[1];
-                __syncthreads();
+                p0 = bcast[0];
+                p1 = bcast[1];
                 if (epoch == 0) {
                     // every workgroup has posted evaluation 0 of this step, so every workgroup is done with the previous
                     // step's slots (the other parity): back to "not posted" for the step after this one, and acknowledged
@@ -345,6 +371,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_sweep4(const SweepArgs A) {
         };
 
         // ---- Optimization::minimizeNewton (optimization.cpp:388-465) as the state machine of iqhip_internal.h
+        unsigned long long tk2 = prof ? wall_clock64() : 0;
         NewtonState ns;
         newton_init(ns, st.xguess, A.x1, A.x2, A.xacc, A.max_steps);
         while (!ns.done && !s_fail) {
@@ -352,6 +379,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_sweep4(const SweepArgs A) {
             eval_at(ns.rts, 0, pdf, pddf);
             newton_update(ns, pdf, pddf);
         }
+        unsigned long long tk3 = prof ? wall_clock64() : 0;
         double result = ns.result, diverged = 0.0;
         // "newton raphson diverged, reset" (phylotree.cpp:2167-2176)
         if (A.diverge_x > 0.0 && ns.status == 0 && !s_fail && result > A.diverge_x) {
@@ -374,8 +402,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_sweep4(const SweepArgs A) {
                 o[5] = 0.0;
             }
         }
+        if (prof) {
+            const unsigned long long tk4 = wall_clock64();
+            pt[0] += tk1 - tk0; pt[1] += tk2 - tk1; pt[2] += tk3 - tk2; pt[3] += tk4 - tk3;
+            pt[4] += (unsigned long long)st.nops; pt[5] += (unsigned long long)ns.neval; pt[6] += 1;
+        }
         if (s_fail) break;   // (the exchange gave up: every later length would be garbage; the host finishes step by step)
     }
+    if (prof)
+        for (int q = 0; q < 8; q++) A.prof[q] = pt[q];
     if (s_fail && blockIdx.x == 0 && threadIdx.x == 0)
         for (int j = 0; j < A.nsteps; j++)
             if (A.out[(size_t)j * 6 + 3] == 0.0 && A.out[(size_t)j * 6 + 2] == 0.0) A.out[(size_t)j * 6 + 3] = 4.0;
@@ -384,7 +419,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_sweep4(const SweepArgs A) {
 template <int C>
 static hipError_t launch_sweep_c(iqhip_engine *e, SweepArgs &A, int grid, bool reg, int waves) {
     constexpr int B = 4 * C;
-    const size_t lds = (size_t)(128 + 2 * B + 10 * B + 3 * B + 16 + 2 + A.nsteps) * sizeof(double);
+    const size_t lds = (size_t)(128 + 2 * B + 10 * B + 32 + 4 + 2 * B + 4 + C + 16 + (waves == 8 ? 8 : 4) * 3 * B + A.nsteps + 2) * sizeof(double);
     if (waves == 8) hipLaunchKernelGGL((k_sweep4<C, true, 8>), dim3(1), dim3(512), lds, e->stream, A);
     else if (reg) hipLaunchKernelGGL((k_sweep4<C, true, 4>), dim3(grid), dim3(256), lds, e->stream, A);
     else hipLaunchKernelGGL((k_sweep4<C, false, 4>), dim3(grid), dim3(256), lds, e->stream, A);
@@ -431,6 +466,19 @@ hipError_t launch_sweep4(iqhip_engine *e, const SweepOp *d_ops, const SweepStep 
     A.max_steps = max_steps;
     A.posts = posts;
     A.out = out;
+    static const bool dbg = getenv("IQHIP_DEBUG_SWEEP") != nullptr;
+    static unsigned long long *d_prof = nullptr;
+    if (dbg && !d_prof) (void)hipMalloc((void **)&d_prof, 8 * sizeof(unsigned long long));
+    A.prof = dbg ? d_prof : nullptr;
+    struct ProfPrint {   // (debug aid: the previous launch's split is printed when the next one is made / at exit)
+        static void show(unsigned long long *d) {
+            unsigned long long h[8];
+            if (hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) != hipSuccess || h[6] == 0) return;
+            fprintf(stderr, "[iqhip] k_sweep4 workgroup 0: %llu steps, %llu node updates %.2f us each, theta %.2f us, %llu evaluations %.2f us each, tail %.2f us per step\n",
+                    h[6], h[4], h[4] ? h[0] * 0.01 / h[4] : 0.0, h[1] * 0.01 / h[6], h[5], h[5] ? h[2] * 0.01 / h[5] : 0.0, h[3] * 0.01 / h[6]);
+        }
+    };
+    if (dbg && d_prof) { (void)hipDeviceSynchronize(); ProfPrint::show(d_prof); (void)hipMemset(d_prof, 0, 8 * sizeof(unsigned long long)); }
     const bool reg = e->ntiles <= (int64_t)grid * waves;
     switch (e->ncat) {
         case 1: return launch_sweep_c<1>(e, A, grid, reg, waves);

@@ -28,11 +28,7 @@ __device__ __forceinline__ const CONST_AS T *as_const(const T *p) {
     return (const CONST_AS T *)(p);
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum64(v); }
 
 // ---------------------------------------------------------------------------------------
 // child access for the 4-state path
