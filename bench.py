@@ -227,8 +227,12 @@ def run_workload(args, D, pkg, synth, workload, steps, warmup, with_cpu_baseline
     # a further pass of the same steps (kept out of the timed region: two event records per step)
     lib.iqhip_timing_enable(eng, 1)
     ntimed = min(max(steps, 20), 100)
+    ch_built0, ch_ops0 = C.c_int64(), C.c_int64()
+    lib.iqhip_debug_cherry_tables(eng, C.byref(ch_built0), C.byref(ch_ops0))
     for _ in range(ntimed):
         step()
+    ch_built1, ch_ops1 = C.c_int64(), C.c_int64()
+    lib.iqhip_debug_cherry_tables(eng, C.byref(ch_built1), C.byref(ch_ops1))
     avg_ms, launches = C.c_double(), C.c_int64()
     lib.iqhip_timing_read(eng, C.byref(avg_ms), C.byref(launches), 1)
     coll_us, coll_n = C.c_double(), C.c_int64()
@@ -269,8 +273,13 @@ def run_workload(args, D, pkg, synth, workload, steps, warmup, with_cpu_baseline
     gbs = lambda nbytes: nbytes / kern_s / 1e9 if kern_s > 0 else 0.0   # noqa: E731
     tfl = algo_flops / kern_s / 1e12 if kern_s > 0 else 0.0
     hbm = {"achieved": gbs(phys_bytes), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs(phys_bytes) / HBM_PEAK_GBS}
+    # (algorithmic flops: what SURVEY 8(d)'s formula asks for, leaf children as look-ups.  The 20-state kernel runs leaf
+    # children of leaf + internal nodes on the matrix pipe (more than the formula) and answers leaf-leaf nodes from cherry
+    # tables (none of the formula's contraction for them): node_updates_from_cherry_tables says how many per traversal)
     mfma = {"achieved": tfl, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / MFMA_F64_PEAK_TFLOPS,
-            "flops_per_traversal": algo_flops}
+            "flops_per_traversal": algo_flops, "flops_are": "algorithmic (SURVEY 8d), not executed",
+            "node_updates_from_cherry_tables": (ch_ops1.value - ch_ops0.value) / float(ntimed),
+            "cherry_tables_rebuilt_in_timed_steps": ch_built1.value - ch_built0.value}
     if nst == 64:
         roof = dict(bound="mfma", **mfma)
         roof["hbm"] = hbm

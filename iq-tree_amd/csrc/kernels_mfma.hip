@@ -598,8 +598,10 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
     }
     // CHILD_HOLD (20 states): a result parked in LDS by the op that produced it (push_hold), in the tile layout
     // [c][row][16 patterns], so that k-step s of category c is the 64 consecutive doubles at (c N + 4 s) 16
+    // (two waves per tile could park their own categories -- measured: the extra state costs that kernel 33 spilled registers,
+    // 1.62 vs 1.10 ms with the form in every stage, profiles/r03/experiments.txt)
     constexpr bool HOLDS = (N < 64) && (CS == 1);
-    LDS_AS double *const hold = HOLDS && A.hold_off >= 0 ? (LDS_AS double *)(smem + A.hold_off) + (size_t)wave * 16 * B + lane : nullptr;
+    LDS_AS double *const hold = HOLDS && A.hold_off >= 0 ? (LDS_AS double *)(smem + A.hold_off) + (size_t)(wave / CS) * 16 * B + lane : nullptr;
     int hold_sc = 0;
     int k = k_begin;
     while (k < k_end) {
@@ -957,14 +959,31 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
                 if (nz) lmax = 1;
             }
             lmax = group_max_u(lmax);
-            if constexpr (CS > 1) {  // maximum over the categories held by the other waves of this tile
-                __shared__ unsigned s_lmax[2][WG / 64][16];
-                const int par = k & 1;
-                if (g == 0) s_lmax[par][wave][p] = lmax;
-                __syncthreads();
-                const int w0 = (wave / CS) * CS;
+            if constexpr (CS > 1) {
+                // Maximum over the categories held by the other waves of this tile -- without a workgroup barrier: a pattern
+                // is rescaled only if EVERY category is below the threshold, so a wave whose own maximum is at or above it
+                // (nearly always) knows the answer without its partners.  Every wave posts its maxima and then a tag (the
+                // LDS performs a wave's operations in order); only a wave that has a candidate pattern waits for its
+                // partners' tags of this op.  Ring of 32 ops: the waves of a workgroup meet at every chunk start, and a
+                // chunk has at most 32 ops (engine.hip), so a slot is never overwritten before it has been read.
+                __shared__ unsigned s_lmax[32][WG / 64][16];
+                __shared__ int s_tag[32][WG / 64];
+                const int slot = k & 31;
+                if (g == 0) s_lmax[slot][wave][p] = lmax;
+                // (relaxed: a release here would wait for the op's result stores, which the tag says nothing about)
+                if (lane == 0) __hip_atomic_store(&s_tag[slot][wave], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const bool cand = !(leafL && leafR) && ((no_scale == 2 && lmax == 0) ||
+                                                        (lmax < kScalingThresholdHi && invar == 0.0 && no_scale != 1));
+                if (__any(cand)) {
+                    const int w0 = (wave / CS) * CS;
 #pragma unroll
-                for (int q = 0; q < CS; q++) lmax = max(lmax, s_lmax[par][w0 + q][p]);
+                    for (int q = 0; q < CS; q++) {
+                        if (w0 + q == wave) continue;
+                        while (__hip_atomic_load(&s_tag[slot][w0 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != k + 1)
+                            __builtin_amdgcn_s_sleep(1);
+                        lmax = max(lmax, s_lmax[slot][w0 + q][p]);
+                    }
+                }
             }
 #if defined(IQHIP_MFMA_ABLATE_NOLOAD) || defined(IQHIP_MFMA_ABLATE_NOSTORE)
             const bool zero = false;
@@ -1448,9 +1467,9 @@ static hipError_t launch_trav_m2(iqhip_engine *e, TravMArgs &A) {
     const int nx = e->state_unknown + 1 - N;
     size_t lds = (size_t)(mfma2_fixed_lds_doubles(N) + nx * N + e->plan_lds_doubles) * sizeof(double);
     A.hold_off = -1;
-    if (N < 64 && CS == 1 && e->plan_nhold > 0) {   // parking places: one tile vector (16 patterns x block) per wave
+    if (N < 64 && CS == 1 && e->plan_nhold > 0) {   // parking places: one tile vector (16 patterns x block) per tile
         A.hold_off = (int)(lds / sizeof(double));
-        lds += (size_t)(WG / 64) * 16 * e->block * sizeof(double);
+        lds += (size_t)(WG / 64 / CS) * 16 * e->block * sizeof(double);
     }
     static bool attr_set = false;
     if (!attr_set) {
