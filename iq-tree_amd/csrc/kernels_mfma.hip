@@ -538,6 +538,13 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
         for (int t = threadIdx.x; t < nx * N; t += WG) sTipx[t] = A.tip[N * N + t];
     }
 
+    // several waves per tile: ring of posted scaling maxima and their tags (see the op tail); the first chunk's barrier
+    // comes before any op
+    __shared__ unsigned s_lmax[CS > 1 ? 32 : 1][WG / 64][16];
+    __shared__ int s_tag[CS > 1 ? 32 : 1][WG / 64];
+    if constexpr (CS > 1) {
+        for (int t = threadIdx.x; t < 32 * (WG / 64); t += WG) (&s_tag[0][0])[t] = 0;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seg = vblock / A.ngroups;  // scalar
@@ -965,12 +972,15 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
                 // (nearly always) knows the answer without its partners.  Every wave posts its maxima and then a tag (the
                 // LDS performs a wave's operations in order); only a wave that has a candidate pattern waits for its
                 // partners' tags of this op.  Ring of 32 ops: the waves of a workgroup meet at every chunk start, and a
-                // chunk has at most 32 ops (engine.hip), so a slot is never overwritten before it has been read.
-                __shared__ unsigned s_lmax[32][WG / 64][16];
-                __shared__ int s_tag[32][WG / 64];
+                // chunk has at most 32 ops (engine.hip), so a slot is never overwritten before it has been read.  The tags
+                // start at zero (cleared when the workgroup starts: a workgroup that ran on this CU before has left the
+                // same op numbers in the same LDS words).
                 const int slot = k & 31;
                 if (g == 0) s_lmax[slot][wave][p] = lmax;
-                // (relaxed: a release here would wait for the op's result stores, which the tag says nothing about)
+                // values before tag: the LDS performs a wave's operations in order, so only the COMPILER has to be told (a
+                // wavefront-scope fence emits nothing; a workgroup-scope release would also wait for the op's result stores,
+                // which the tag says nothing about)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 if (lane == 0) __hip_atomic_store(&s_tag[slot][wave], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const bool cand = !(leafL && leafR) && ((no_scale == 2 && lmax == 0) ||
                                                         (lmax < kScalingThresholdHi && invar == 0.0 && no_scale != 1));
@@ -979,9 +989,12 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
 #pragma unroll
                     for (int q = 0; q < CS; q++) {
                         if (w0 + q == wave) continue;
-                        while (__hip_atomic_load(&s_tag[slot][w0 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != k + 1)
+                        // (the partner is resident and posts unconditionally; bounded all the same: no wait may hang the chip)
+                        for (int spins = 0; spins < (1 << 22) &&
+                             __hip_atomic_load(&s_tag[slot][w0 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != k + 1; spins++)
                             __builtin_amdgcn_s_sleep(1);
-                        lmax = max(lmax, s_lmax[slot][w0 + q][p]);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (tag before values, for the compiler)
+                        lmax = max(lmax, *(volatile unsigned *)&s_lmax[slot][w0 + q][p]);
                     }
                 }
             }
