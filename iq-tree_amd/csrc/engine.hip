@@ -1311,8 +1311,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
             const int nleaf = (d.left_kind == CHILD_LEAF) + (d.right_kind == CHILD_LEAF);
             const int need = szl + szr + (e->mfma ? 0 : nleaf * e->wg_size / 8);
             if (need > budget) return fail(IQHIP_ERR_UNSUPPORTED, "nstates*ncat too large for the LDS plan regions");
-            // (matrix-core kernels with several waves per tile post their scaling maxima in a ring of 32 ops per chunk)
-            if ((used + need > budget || seg_of[k] != seg_of[k - (k > 0)] || (e->mfma && k - chunk_start >= 32)) && k > chunk_start) {
+            if ((used + need > budget || seg_of[k] != seg_of[k - (k > 0)]) && k > chunk_start) {
                 e->h_ops[chunk_start].chunk_nops = k - chunk_start;
                 chunk_start = k;
                 used = e->mfma ? 0 : e->wg_size / 8;  // slot 0

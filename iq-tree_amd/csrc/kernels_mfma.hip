@@ -538,13 +538,6 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
         for (int t = threadIdx.x; t < nx * N; t += WG) sTipx[t] = A.tip[N * N + t];
     }
 
-    // several waves per tile: ring of posted scaling maxima and their tags (see the op tail); the first chunk's barrier
-    // comes before any op
-    __shared__ unsigned s_lmax[CS > 1 ? 32 : 1][WG / 64][16];
-    __shared__ int s_tag[CS > 1 ? 32 : 1][WG / 64];
-    if constexpr (CS > 1) {
-        for (int t = threadIdx.x; t < 32 * (WG / 64); t += WG) (&s_tag[0][0])[t] = 0;
-    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seg = vblock / A.ngroups;  // scalar
@@ -967,36 +960,16 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
             }
             lmax = group_max_u(lmax);
             if constexpr (CS > 1) {
-                // Maximum over the categories held by the other waves of this tile -- without a workgroup barrier: a pattern
-                // is rescaled only if EVERY category is below the threshold, so a wave whose own maximum is at or above it
-                // (nearly always) knows the answer without its partners.  Every wave posts its maxima and then a tag (the
-                // LDS performs a wave's operations in order); only a wave that has a candidate pattern waits for its
-                // partners' tags of this op.  Ring of 32 ops: the waves of a workgroup meet at every chunk start, and a
-                // chunk has at most 32 ops (engine.hip), so a slot is never overwritten before it has been read.  The tags
-                // start at zero (cleared when the workgroup starts: a workgroup that ran on this CU before has left the
-                // same op numbers in the same LDS words).
-                const int slot = k & 31;
-                if (g == 0) s_lmax[slot][wave][p] = lmax;
-                // values before tag: the LDS performs a wave's operations in order, so only the COMPILER has to be told (a
-                // wavefront-scope fence emits nothing; a workgroup-scope release would also wait for the op's result stores,
-                // which the tag says nothing about)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                if (lane == 0) __hip_atomic_store(&s_tag[slot][wave], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const bool cand = !(leafL && leafR) && ((no_scale == 2 && lmax == 0) ||
-                                                        (lmax < kScalingThresholdHi && invar == 0.0 && no_scale != 1));
-                if (__any(cand)) {
-                    const int w0 = (wave / CS) * CS;
+                // maximum over the categories held by the other waves of this tile (LDS + one workgroup barrier per op; a
+                // barrier-free exchange -- maxima posted with tags, a wave waits for its partners only when it has a candidate
+                // pattern -- was measured equal, 199 vs 197 us for the top stage, and is not worth its moving parts)
+                __shared__ unsigned s_lmax[2][WG / 64][16];
+                const int par = k & 1;
+                if (g == 0) s_lmax[par][wave][p] = lmax;
+                __syncthreads();
+                const int w0 = (wave / CS) * CS;
 #pragma unroll
-                    for (int q = 0; q < CS; q++) {
-                        if (w0 + q == wave) continue;
-                        // (the partner is resident and posts unconditionally; bounded all the same: no wait may hang the chip)
-                        for (int spins = 0; spins < (1 << 22) &&
-                             __hip_atomic_load(&s_tag[slot][w0 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != k + 1; spins++)
-                            __builtin_amdgcn_s_sleep(1);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (tag before values, for the compiler)
-                        lmax = max(lmax, *(volatile unsigned *)&s_lmax[slot][w0 + q][p]);
-                    }
-                }
+                for (int q = 0; q < CS; q++) lmax = max(lmax, s_lmax[par][w0 + q][p]);
             }
 #if defined(IQHIP_MFMA_ABLATE_NOLOAD) || defined(IQHIP_MFMA_ABLATE_NOSTORE)
             const bool zero = false;
@@ -1048,15 +1021,6 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
 template <int N, int C, int WG, int CS = 1, bool TAB = false>
 __global__ __launch_bounds__(WG, (N == 20 && C == 2 && CS == 2) ? 3 : 2) void k_traverse_mfma2(const TravMArgs A) {
     trav_mfma2_body<N, C, WG, CS, TAB>(A, (int)blockIdx.x);
-}
-
-// The mixed-role top stage of 20 states x 4 categories: the two-waves-per-tile form fills whole rounds of the chip (3
-// workgroups per CU x 2 tiles); the few tiles beyond the last whole round -- 53 of 3125 at 50 000 patterns, which used to
-// cost a third round of a nearly empty chip -- run as one wave per category (half the chain per wave) in workgroups that
-// are dispatched first.  Same per-pattern arithmetic in both roles: same bits.
-__global__ __launch_bounds__(256, 3) void k_traverse_mfma_top20(const TravMArgs F, const int nrest, const TravMArgs R, const int64_t tile0R) {
-    if ((int)blockIdx.x < nrest) trav_mfma2_body<20, 1, 256, 4, false>(R, (int)blockIdx.x, tile0R);
-    else trav_mfma2_body<20, 2, 256, 2, false>(F, (int)blockIdx.x - nrest);
 }
 
 template <int N, bool MIX>
@@ -1503,31 +1467,6 @@ static hipError_t launch_trav_m2(iqhip_engine *e, TravMArgs &A) {
     return hipGetLastError();
 }
 
-static hipError_t launch_trav_top20(iqhip_engine *e, TravMArgs &A, int nfull_wg) {
-    const int nx = e->state_unknown + 1 - 20;
-    const size_t lds = (size_t)(mfma2_fixed_lds_doubles(20) + nx * 20 + e->plan_lds_doubles) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma_top20), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
-    }
-    A.hold_off = -1;
-    if (e->plan_small && A.nsegs_launch == 1) {
-        A.small_plan = 1;
-        A.small_segs[0] = 0;
-        A.small_segs[1] = e->plan_small_nops;
-        for (int q = 0; q < kSmallPlanOps; q++) A.small_ops[q] = e->h_ops[q];
-    }
-    TravMArgs F = A, R = A;
-    F.ntiles = (int64_t)nfull_wg * 2;
-    F.ngroups = nfull_wg;
-    const int nrest = (int)(A.ntiles - F.ntiles);
-    R.ngroups = nrest;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(k_traverse_mfma_top20, dim3((unsigned)(nrest + nfull_wg)), dim3(256), lds, e->stream, F, nrest, R, F.ntiles);
-    return hipGetLastError();
-}
-
 // the mixed-role top stage (k_traverse_mfma_top64): full-chain workgroups for whole rounds of the chip, row-split
 // workgroups for the tiles that are left over
 template <bool TAB>
@@ -1647,14 +1586,9 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs
         }
         if (e->n == 20 && e->ncat == 4) {
             if (e->cat_split) return launch_trav_m2<20, 1, 4>(e, A);
-            if (e->top_cs2 && top_stage) {
-                // whole rounds of two-waves-per-tile workgroups; a small remainder as one wave per category (launch_trav_top20)
-                const int64_t per_round = (int64_t)e->num_cus * 3 * 2;
-                const int64_t rounds = e->ntiles / per_round, rest = e->ntiles - rounds * per_round;
-                if (e->mixed_top && nsegs == 1 && rounds >= 1 && rest > 0 && rest <= per_round / 4)
-                    return launch_trav_top20(e, A, (int)(rounds * e->num_cus * 3));
-                return launch_trav_m2<20, 2, 2>(e, A);
-            }
+            // (a mixed-role launch -- whole rounds as two waves per tile, the 53 tiles beyond them as one wave per category --
+            // was measured against this one on one box: top stage 220 vs 199 us, profiles/r03/experiments.txt; not kept)
+            if (e->top_cs2 && top_stage) return launch_trav_m2<20, 2, 2>(e, A);
             return launch_trav_m2<20, 4>(e, A);
         }
         if (e->n == 20 && e->ncat == 1) return launch_trav_m2<20, 1>(e, A);
