@@ -1023,6 +1023,41 @@ __global__ __launch_bounds__(WG, (N == 20 && C == 2 && CS == 2) ? 3 : 2) void k_
     trav_mfma2_body<N, C, WG, CS, TAB>(A, (int)blockIdx.x);
 }
 
+// Mixed-role top stage of 20 states x 4 categories (IQHIP_MIXED_TOP=0 switches it off): whole rounds of the chip as two waves
+// per tile; the few tiles beyond the last whole round (53 of 3125 at 50 000 patterns: a third round on a nearly empty chip, 15 %
+// of the top stage in the wave trace) as one wave per category, dispatched LAST, so that the tail is a quarter chain per wave:
+// top stage 200 -> 187 us on one box (tools/top_stage_ab.sh).  Dispatched FIRST the same workgroups push 53 two-wave
+// workgroups into a third round: 220 us.  Same per-pattern arithmetic in both roles: same bits.
+__global__ __launch_bounds__(256, 3) void k_traverse_mfma_top20(const TravMArgs F, const int nfull, const TravMArgs R, const int64_t tile0R) {
+    if ((int)blockIdx.x < nfull) trav_mfma2_body<20, 2, 256, 2, false>(F, (int)blockIdx.x);
+    else trav_mfma2_body<20, 1, 256, 4, false>(R, (int)blockIdx.x - nfull, tile0R);
+}
+
+static hipError_t launch_trav_top20(iqhip_engine *e, TravMArgs &A, int nfull_wg) {
+    const int nx = e->state_unknown + 1 - 20;
+    const size_t lds = (size_t)(mfma2_fixed_lds_doubles(20) + nx * 20 + e->plan_lds_doubles) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse_mfma_top20), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    A.hold_off = -1;
+    if (e->plan_small && A.nsegs_launch == 1) {
+        A.small_plan = 1;
+        A.small_segs[0] = 0;
+        A.small_segs[1] = e->plan_small_nops;
+        for (int q = 0; q < kSmallPlanOps; q++) A.small_ops[q] = e->h_ops[q];
+    }
+    TravMArgs F = A, R = A;
+    F.ntiles = (int64_t)nfull_wg * 2;
+    F.ngroups = nfull_wg;
+    const int nrest = (int)(A.ntiles - F.ntiles);
+    R.ngroups = nrest;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_traverse_mfma_top20, dim3((unsigned)(nrest + nfull_wg)), dim3(256), lds, e->stream, F, nfull_wg, R, F.ntiles);
+    return hipGetLastError();
+}
+
 template <int N, bool MIX>
 static hipError_t launch_trav_m(iqhip_engine *e, TravMArgs &A) {
     constexpr int MT = (N + 15) / 16, KS = N / 4, WG = 256;
@@ -1588,7 +1623,14 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs
             if (e->cat_split) return launch_trav_m2<20, 1, 4>(e, A);
             // (a mixed-role launch -- whole rounds as two waves per tile, the 53 tiles beyond them as one wave per category --
             // was measured against this one on one box: top stage 220 vs 199 us, profiles/r03/experiments.txt; not kept)
-            if (e->top_cs2 && top_stage) return launch_trav_m2<20, 2, 2>(e, A);
+            if (e->top_cs2 && top_stage) {
+                const bool mixed20 = e->mixed_top;
+                const int64_t per_round = (int64_t)e->num_cus * 3 * 2;
+                const int64_t rounds = e->ntiles / per_round, rest = e->ntiles - rounds * per_round;
+                if (mixed20 && nsegs == 1 && rounds >= 1 && rest > 0 && rest <= per_round / 4)
+                    return launch_trav_top20(e, A, (int)(rounds * e->num_cus * 3));
+                return launch_trav_m2<20, 2, 2>(e, A);
+            }
             return launch_trav_m2<20, 4>(e, A);
         }
         if (e->n == 20 && e->ncat == 1) return launch_trav_m2<20, 1>(e, A);

@@ -127,3 +127,30 @@ def test_small_alignments_and_other_shapes_use_no_tables(pkg, synth, oracle):
     t = make(pkg, nwk, pat, freq, synth.ptn_invar_for(pat, model), model, 0, 64, 2)
     t.compute_likelihood()
     assert counters(pkg, t) == (0, 0)
+
+
+@pytest.mark.parametrize("ntaxa", [9, 18])
+def test_mixed_role_top_stage_gives_the_same_bits(pkg, synth, oracle, monkeypatch, ntaxa):
+    """20 states x 4 categories, top stage of a plan (kernels_mfma.hip k_traverse_mfma_top20): whole rounds of the chip as two
+    waves per tile, the tiles beyond them as one wave per category -- 1563 tiles = one round of 1536 + 27.  Same vectors
+    bit for bit as the single-role launch (IQHIP_MIXED_TOP=0), lnL equal to the oracle's; unstaged (9 taxa) and staged."""
+    model = synth.random_reversible_model(20, 61, alpha=0.7, ncat=4)
+    su = oracle.state_unknown_for(20, 1)
+    nwk = synth.random_tree_newick(ntaxa, 62, 0.02, 0.3)
+    pat = np.ascontiguousarray(synth.simulate_alignment(nwk, model, 25000, 63, 0.02, su))   # (sites as they are: 1563 tiles)
+    freq = np.ones(25000)
+    invar = synth.ptn_invar_for(pat, model)
+    ot = oracle.OracleTree(nwk, 20, 1, pat, freq, invar, model)
+    ref, _ = ot.likelihood()
+    res = []
+    for mixed in ("0", "1"):
+        monkeypatch.setenv("IQHIP_MIXED_TOP", mixed)
+        t = make(pkg, nwk, pat, freq, invar, model, pkg.LM_ALL_BRANCH)
+        res.append((t.compute_likelihood(), vectors(t, ot)))
+    monkeypatch.delenv("IQHIP_MIXED_TOP")
+    (l0, v0), (l1, v1) = res
+    assert l0 == l1 and abs(l1 - ref) <= 1e-9 * abs(ref)
+    assert v0.keys() == v1.keys() and len(v0) >= ntaxa - 3
+    for k in v0:
+        assert np.array_equal(v0[k][0], v1[k][0]), k
+        assert np.array_equal(v0[k][1], v1[k][1]), k
