@@ -1621,9 +1621,8 @@ hipError_t launch_traverse_mfma(iqhip_engine *e, const int *seg_table, int nsegs
         }
         if (e->n == 20 && e->ncat == 4) {
             if (e->cat_split) return launch_trav_m2<20, 1, 4>(e, A);
-            // (a mixed-role launch -- whole rounds as two waves per tile, the 53 tiles beyond them as one wave per category --
-            // was measured against this one on one box: top stage 220 vs 199 us, profiles/r03/experiments.txt; not kept)
             if (e->top_cs2 && top_stage) {
+                // whole rounds of two-waves-per-tile workgroups; a small remainder as one wave per category (launch_trav_top20)
                 const bool mixed20 = e->mixed_top;
                 const int64_t per_round = (int64_t)e->num_cus * 3 * 2;
                 const int64_t rounds = e->ntiles / per_round, rest = e->ntiles - rounds * per_round;
