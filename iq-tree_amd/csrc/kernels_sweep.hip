@@ -416,6 +416,25 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_sweep4(const SweepArgs A) {
             if (A.out[(size_t)j * 6 + 3] == 0.0 && A.out[(size_t)j * 6 + 2] == 0.0) A.out[(size_t)j * 6 + 3] = 4.0;
 }
 
+// IQHIP_DEBUG_SWEEP: workgroup 0's split of the persistent kernel's time (100 MHz clock); the previous launch's figures are
+// printed when the next sweep is launched
+static unsigned long long *sweep_prof_buffer() {
+    static const bool dbg = getenv("IQHIP_DEBUG_SWEEP") != nullptr;
+    static unsigned long long *d_prof = nullptr;
+    if (!dbg) return nullptr;
+    if (!d_prof) {
+        if (hipMalloc((void **)&d_prof, 8 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+        (void)hipMemset(d_prof, 0, 8 * sizeof(unsigned long long));
+        return d_prof;
+    }
+    unsigned long long h[8];
+    if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(h, d_prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[6] != 0)
+        fprintf(stderr, "[iqhip] k_sweep4 workgroup 0: %llu steps, %llu node updates %.2f us each, theta %.2f us, %llu evaluations %.2f us each, tail %.2f us per step\n",
+                h[6], h[4], h[4] ? h[0] * 0.01 / h[4] : 0.0, h[1] * 0.01 / h[6], h[5], h[5] ? h[2] * 0.01 / h[5] : 0.0, h[3] * 0.01 / h[6]);
+    (void)hipMemset(d_prof, 0, 8 * sizeof(unsigned long long));
+    return d_prof;
+}
+
 template <int C>
 static hipError_t launch_sweep_c(iqhip_engine *e, SweepArgs &A, int grid, bool reg, int waves) {
     constexpr int B = 4 * C;
@@ -466,19 +485,7 @@ hipError_t launch_sweep4(iqhip_engine *e, const SweepOp *d_ops, const SweepStep 
     A.max_steps = max_steps;
     A.posts = posts;
     A.out = out;
-    static const bool dbg = getenv("IQHIP_DEBUG_SWEEP") != nullptr;
-    static unsigned long long *d_prof = nullptr;
-    if (dbg && !d_prof) (void)hipMalloc((void **)&d_prof, 8 * sizeof(unsigned long long));
-    A.prof = dbg ? d_prof : nullptr;
-    struct ProfPrint {   // (debug aid: the previous launch's split is printed when the next one is made / at exit)
-        static void show(unsigned long long *d) {
-            unsigned long long h[8];
-            if (hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) != hipSuccess || h[6] == 0) return;
-            fprintf(stderr, "[iqhip] k_sweep4 workgroup 0: %llu steps, %llu node updates %.2f us each, theta %.2f us, %llu evaluations %.2f us each, tail %.2f us per step\n",
-                    h[6], h[4], h[4] ? h[0] * 0.01 / h[4] : 0.0, h[1] * 0.01 / h[6], h[5], h[5] ? h[2] * 0.01 / h[5] : 0.0, h[3] * 0.01 / h[6]);
-        }
-    };
-    if (dbg && d_prof) { (void)hipDeviceSynchronize(); ProfPrint::show(d_prof); (void)hipMemset(d_prof, 0, 8 * sizeof(unsigned long long)); }
+    A.prof = sweep_prof_buffer();
     const bool reg = e->ntiles <= (int64_t)grid * waves;
     switch (e->ncat) {
         case 1: return launch_sweep_c<1>(e, A, grid, reg, waves);

@@ -22,12 +22,16 @@ for case in range(ncases):
         mixture = False
         ncat = int(rng.choice([4, 4, 1])) if n == 20 else 1
         ntaxa = int(rng.integers(14, 70))
-        nptn = int(rng.choice([5000, 9000, 17000, 21000]))
+        nptn = int(rng.choice([5000, 9000, 17000, 21000, 25500, 27000]))   # (>= 8192: cherry tables; >= 24576: mixed-role top stage)
     deep = rng.random() < 0.2
     pinv = float(rng.choice([0.0, 0.0, 0.15])) if not mixture else 0.0
     seed = int(rng.integers(1, 10 ** 6))
-    for k in ("IQHIP_SPLIT", "IQHIP_LANE_SPLIT", "IQHIP_CAT_SPLIT", "IQHIP_ROW_SPLIT", "IQHIP_LEAF_TABLES"):
+    for k in ("IQHIP_SPLIT", "IQHIP_LANE_SPLIT", "IQHIP_CAT_SPLIT", "IQHIP_ROW_SPLIT", "IQHIP_LEAF_TABLES", "IQHIP_CHERRY_TABLES",
+              "IQHIP_MIXED_TOP", "IQHIP_TOP_CS2"):
         os.environ.pop(k, None)
+    if rng.random() < 0.2: os.environ["IQHIP_CHERRY_TABLES"] = "0"
+    if rng.random() < 0.2: os.environ["IQHIP_MIXED_TOP"] = "0"
+    if rng.random() < 0.15: os.environ["IQHIP_TOP_CS2"] = str(int(rng.choice([0, 1])))
     if rng.random() < 0.4: os.environ["IQHIP_SPLIT"] = str(int(rng.choice([0, 2, 3, 5, 9])))
     if rng.random() < 0.3: os.environ["IQHIP_LANE_SPLIT"] = str(int(rng.choice([1, 2])))
     if rng.random() < 0.3: os.environ["IQHIP_CAT_SPLIT"] = str(int(rng.choice([0, 1])))
