@@ -9,6 +9,7 @@ def free_mb():
     hip.hipMemGetInfo(C.byref(f), C.byref(t))
     return f.value / 1e6
 cases = [(4, 0, synth.gtr_model(), 30000), (20, 1, synth.random_reversible_model(20, 3, ncat=4), 3000),
+         (20, 1, synth.random_reversible_model(20, 3, ncat=4), 9500),   # (>= 8192 patterns: cherry tables and their pair engine)
          (20, 1, synth.mixture_model(20, 3, 5, ncat=4), 3000), (64, 2, synth.random_reversible_model(64, 4, alpha=None, ncat=1), 2000)]
 base = None
 for rep in range(6):
