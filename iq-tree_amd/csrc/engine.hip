@@ -618,7 +618,7 @@ static int set_model_common(iqhip_engine *e, int nclass, const int32_t *cat_clas
 // cherry tables (DevOp::cherry): which engines use them, and their pair engine
 // ---------------------------------------------------------------------------------------
 static bool cherry_candidate(const iqhip_engine *e) {
-    if (!e || !e->cherry_on || e->planner || !e->shards.empty() || e->ablate) return false;
+    if (!e || !e->cherry_on || !e->shards.empty() || e->ablate) return false;   // (a planning-only engine plans them too)
     if (!e->mfma_pipelined_ok || e->n_user != e->n) return false;
     if (e->n == 20) return e->ncat == 4 && !e->leaf_tables && !e->cat_split && e->nptn_pad >= 8 * 1024;
     return false;
@@ -1227,10 +1227,15 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
     e->plan_cherry_jobs.clear();
     e->plan_uses_cherry = false;
     e->plan_cherry_model = e->model_version;
-    if (cherry_candidate(e) && e->mfma_pipelined && e->pair && e->cherry_model_synced && nops >= 8) {
+    // (planning-only engine: the tables are never built, their slots are fake addresses like every other buffer)
+    const bool have_pair = e->planner ? e->cherry_s2 > 0 : (e->pair && e->cherry_model_synced);
+    if (cherry_candidate(e) && e->mfma_pipelined && have_pair && nops >= 8) {
         const size_t per = (size_t)e->cherry_npairs * B;
         const size_t want = (size_t)2 * e->ntaxa + 16;
-        if (e->cherry_cap < want) {
+        if (e->cherry_cap < want && e->planner) {
+            e->d_cherry_tab = fake_alloc<double>(e, want * per);
+            e->cherry_cap = want;
+        } else if (e->cherry_cap < want) {
             HIPCHK(hipStreamSynchronize(e->stream));
             if (e->d_cherry_tab) hipFree(e->d_cherry_tab);
             e->d_cherry_tab = nullptr;
@@ -1366,6 +1371,10 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
             if (!strcmp(br, "tab")) e->h_ops[nops - 1].tabL = nullptr;
             else if (!strcmp(br, "sentinel")) e->h_ops[nops + kSentinels - 1].pf = nullptr;
             else if (!strcmp(br, "states")) e->h_ops[0].sr = nullptr;
+            else if (!strcmp(br, "cherry")) {
+                for (int k = 0; k < nops; k++)
+                    if (e->h_ops[k].cherry) { e->h_ops[k].cherry += 8; break; }   // (inside the buffer, not on a table)
+            }
         }
     }
     if (e->check_plans && !e->ablate) {
@@ -3048,6 +3057,13 @@ extern "C" int iqhip_debug_create_planner(iqhip_engine **out, int nstates, int n
     }
     e->mfma_pipelined = e->mfma_pipelined_ok && nclass == 1;
     e->model_set = e->aln_set = true;
+    {   // cherry tables as cherry_sync_model would set them up
+        const int s2 = state_unknown + 1;
+        if (cherry_candidate(e) && nclass == 1 && s2 * s2 <= 4356 && (int64_t)4 * s2 * s2 <= e->nptn_pad) {
+            e->cherry_s2 = s2;
+            e->cherry_npairs = (int)round_up(s2 * s2, 64);
+        }
+    }
     *out = e;
     return IQHIP_OK;
 }
@@ -3057,5 +3073,12 @@ extern "C" int iqhip_debug_plan(iqhip_engine *e, const iqhip_node_op *ops, int n
     if (!e || !e->planner) return fail(IQHIP_ERR_INVALID, "iqhip_debug_plan needs a planning-only engine");
     if (nops < 0 || (nops > 0 && !ops)) return fail(IQHIP_ERR_INVALID, "bad ops array");
     int last_dst = -1;
-    return build_plan(e, ops, nops, &last_dst, nullptr);
+    const int rc = build_plan(e, ops, nops, &last_dst, nullptr);
+    if (!rc) {   // (what submit_traverse would count: iqhip_debug_cherry_tables)
+        e->cherry_built_total += (int64_t)e->plan_cherry_jobs.size();
+        for (int slot : e->plan_cherry_jobs) e->cherry_slots[slot].model_version = e->model_version;   // ("built")
+        e->plan_cherry_jobs.clear();
+        for (int k = 0; k < nops; k++) e->cherry_ops_total += e->h_ops[k].cherry != nullptr;
+    }
+    return rc;
 }

@@ -64,6 +64,52 @@ def test_plans_satisfy_the_kernel_contract(pkg, synth, monkeypatch, nstates, nca
         lib.iqhip_destroy(e)
 
 
+def test_cherry_tables_are_planned_and_checked(pkg, synth, monkeypatch):
+    """20 states x 4 categories from 8192 patterns on: ops with two leaf children get a slot of the cherry-table buffer
+    (engine.hip build_plan, DevOp::cherry) -- in the unit stages only, one slot per pair of taxa, rebuilt only for new
+    lengths -- and a pointer that is not a slot is refused."""
+    lib = pkg.libiqhip()
+
+    def counters(e):
+        built, ops = C.c_int64(), C.c_int64()
+        assert lib.iqhip_debug_cherry_tables(e, C.byref(built), C.byref(ops)) == 0
+        return built.value, ops.value
+    plan = plan_of(pkg, synth, 100, 41, 20)
+    ncherry = sum(1 for o in plan if o.left_leaf >= 0 and o.right_leaf >= 0)
+    assert ncherry >= 20
+    lib_, e = planner(pkg, 20, 4, 50000, 100)
+    try:
+        assert lib.iqhip_debug_plan(e, plan, len(plan)) == 0, lib.iqhip_last_error()
+        built, ops = counters(e)
+        assert 0 < ops <= ncherry and built == ops          # (the top stage's kernel computes its cherries itself)
+        assert lib.iqhip_debug_plan(e, plan, len(plan)) == 0
+        assert counters(e)[0] == built                      # same plan again: the cached descriptors, nothing scheduled
+        k = next(i for i, o in enumerate(plan) if o.left_leaf >= 0 and o.right_leaf >= 0)
+        plan[k].left_len += 0.125                           # one pendant length changes: one table
+        assert lib.iqhip_debug_plan(e, plan, len(plan)) == 0
+        assert counters(e)[0] in (built, built + 1)         # (+0 if that cherry sits in the top stage)
+    finally:
+        lib.iqhip_destroy(e)
+    for env in ({"IQHIP_CHERRY_TABLES": "0"}, {}):
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        small = env == {}
+        lib_, e = planner(pkg, 20, 4, 5000 if small else 50000, 100)   # switched off / below 8192 patterns: no tables
+        try:
+            assert lib.iqhip_debug_plan(e, plan, len(plan)) == 0
+            assert counters(e) == (0, 0)
+        finally:
+            lib.iqhip_destroy(e)
+        monkeypatch.delenv("IQHIP_CHERRY_TABLES", raising=False)
+    monkeypatch.setenv("IQHIP_DEBUG_BREAK_PLAN", "cherry")
+    lib_, e = planner(pkg, 20, 4, 50000, 100)
+    try:
+        rc = lib.iqhip_debug_plan(e, plan, len(plan))
+        assert rc == 2 and "cherry" in lib.iqhip_last_error().decode(), lib.iqhip_last_error()
+    finally:
+        lib.iqhip_destroy(e)
+
+
 @pytest.mark.parametrize("what,needle", [("tab", "K2 table"), ("sentinel", "pf"), ("states", "state matrix")])
 def test_a_broken_descriptor_is_refused(pkg, synth, monkeypatch, what, needle):
     """the round-2 fault class: a descriptor pointer the op itself does not use is null"""
