@@ -352,11 +352,27 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
         // phase 3: this thread's leaf state bytes of the whole chunk -> LDS.  They are read once per
         // traversal (cold misses); issuing them as one burst pays the miss latency once per chunk
         // instead of once per op and keeps the op loop's VMEM sequence short.
+        // (Unconditional requests, eight ops = sixteen bytes in flight at a time: sl / sr of a non-leaf child point at a valid
+        // row and its slot 0 is never read.  The conditional form -- load, wait, LDS store, next child -- paid one cold miss
+        // per LEAF CHILD instead of per chunk: 87 k of a wave's 313 k cycles per traversal at 66 k patterns, measured with
+        // the shader clock.)
         if (active) {
-            for (int o = 0; o < kn; o++) {
-                const CONST_AS DevOp *d = ops + (k + o);
-                if (d->left_kind == CHILD_LEAF) s_states[d->sl_slot * WG + threadIdx.x] = *(d->sl + poff);
-                if (d->right_kind == CHILD_LEAF) s_states[d->sr_slot * WG + threadIdx.x] = *(d->sr + poff);
+            for (int o0 = 0; o0 < kn; o0 += 8) {
+                uint8_t vl[8], vr[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const CONST_AS DevOp *d = ops + (k + (o0 + j < kn ? o0 + j : kn - 1));
+                    vl[j] = *(d->sl + poff);
+                    vr[j] = *(d->sr + poff);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (o0 + j < kn) {
+                        const CONST_AS DevOp *d = ops + (k + o0 + j);
+                        s_states[d->sl_slot * WG + threadIdx.x] = vl[j];
+                        s_states[d->sr_slot * WG + threadIdx.x] = vr[j];
+                    }
+                }
             }
         }
         __syncthreads();
