@@ -251,6 +251,14 @@ __device__ __forceinline__ void store_vec4_off(double *base, uint32_t voff, cons
 // 4-state kernel is latency / occupancy limited below ~4 waves per SIMD).  The memory layout is
 // unchanged: the lane's categories are rows [2*coff, 2*coff + 2*CL) of the tile.
 // USE_HOLD = false: no HOLD register set (the plan then contains no CHILD_HOLD / push_hold): 2*BL fewer registers
+// -DIQHIP_T4_TRACE (timing study, tools/build_alt.sh t4trace -DIQHIP_T4_TRACE): a few waves split their op loop with the
+// shader clock -- chunk fill / op head / node update / op tail -- and every 100th launch prints the averages
+#ifdef IQHIP_T4_TRACE
+__device__ unsigned long long g_t4[8];
+#define T4_CLK() (t4_on ? (unsigned long long)clock64() : 0ull)
+#else
+#define T4_CLK() 0ull
+#endif
 template <int C, int WG, bool HAS_LOAD, int SP, bool USE_HOLD = true>
 __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
     static_assert(SP == 1 || (SP == 2 && C % 2 == 0), "SP = 2 needs an even category count");
@@ -263,8 +271,12 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
     double *s_reg = smem + 128 + B;   // per (op, child) regions of the current chunk
     uint8_t *s_states = reinterpret_cast<uint8_t *>(s_reg + A.lds_reg_doubles);  // [slot][WG] leaf states
 
+    __shared__ double s_model[32];    // U [16], eigenvalues [4], rates [C <= 8]: the chunk fills read them many times
+    __shared__ int s_opi[64][4];      // per op of a fill pass: LDS offsets of its two regions, is-leaf flags
+    __shared__ double s_opl[64][2];   // ... child branch lengths
     const int nst = A.state_unknown + 1;
     for (int t = threadIdx.x; t < nst * 4; t += WG) s_tip[t] = A.tip[t];
+    for (int t = threadIdx.x; t < 20 + C; t += WG) s_model[t] = t < 16 ? A.evec[t] : (t < 20 ? A.eval[t - 16] : A.rates[t - 20]);
     if (A.has_root && threadIdx.x < B) {
         const int c = threadIdx.x >> 2, i = threadIdx.x & 3;
         s_val[threadIdx.x] = exp(A.eval[i] * (A.rates[c] * A.root.len)) * A.props[c];
@@ -318,55 +330,78 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
                                                    ((nreal & 1) ? soff : (uint32_t)(lane * 2)));
     }
 
+#ifdef IQHIP_T4_TRACE
+    const bool t4_on = (blockIdx.x % 97) == 5 && threadIdx.x == 0;
+    unsigned long long t4_fill = 0, t4_head = 0, t4_upd = 0, t4_tail = 0, t4_n = 0, t4_f1 = 0, t4_f2 = 0;
+#endif
     int k = k_begin;
     while (k < k_end) {
         // ---- fill the LDS regions of the chunk that starts at op k (host-chosen boundaries)
         const int kn = ops[k].chunk_nops;
+        [[maybe_unused]] const unsigned long long c0 = T4_CLK();
         __syncthreads();  // the previous chunk's regions are no longer read
-        for (int t = threadIdx.x; t < kn * 2 * B; t += WG) {  // phase 1: exponentials
-            const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B;
-            const CONST_AS DevOp &d = ops[k + o];
-            const double len = op_child_len(d, child);
-            s_reg[(child ? d.lds_right : d.lds_left) + e] = exp(A.eval[e & 3] * (A.rates[e >> 2] * len));
-        }
-        __syncthreads();
-        for (int t = threadIdx.x; t < kn * 2 * 5 * B; t += WG) {  // phase 2: leaf tables (K2)
-            const int o = t / (10 * B), r = t - o * (10 * B), child = r / (5 * B), q = r - child * (5 * B);
-            const CONST_AS DevOp &d = ops[k + o];
-            if ((child ? d.right_kind : d.left_kind) != CHILD_LEAF) continue;
-            const int row = q / B, e = q - row * B, c = e >> 2, x = e & 3;
-            double *reg = s_reg + (child ? d.lds_right : d.lds_left);
-            double v = 1.0;  // STATE_UNKNOWN row (phylokernel.h:228-232)
-            if (row < 4) {
-                // E = U*ex rounded first, then the reference's (t0+t1)+(t2+t3), all unfused
-                const double e0 = __dmul_rn(A.evec[x * 4 + 0], reg[c * 4 + 0]);
-                const double e1 = __dmul_rn(A.evec[x * 4 + 1], reg[c * 4 + 1]);
-                const double e2 = __dmul_rn(A.evec[x * 4 + 2], reg[c * 4 + 2]);
-                const double e3 = __dmul_rn(A.evec[x * 4 + 3], reg[c * 4 + 3]);
-                const double *tp = s_tip + row * 4;
-                v = __dadd_rn(__dadd_rn(__dmul_rn(e0, tp[0]), __dmul_rn(e1, tp[1])),
-                              __dadd_rn(__dmul_rn(e2, tp[2]), __dmul_rn(e3, tp[3])));
+        // The fill reads every op's descriptor and the model once per table entry: from LDS copies (the descriptors' few
+        // fields staged per pass of 64 ops, eigenvalues / rates / U at kernel start) instead of dependent reads from memory --
+        // those cost 34 k of a wave's 254 k cycles per traversal at 66 k patterns (shader clock; the exponentials themselves
+        // are about 9 k of that).
+        [[maybe_unused]] unsigned long long c0a = T4_CLK();
+        for (int o0 = 0; o0 < kn; o0 += 64) {
+            const int on = kn - o0 < 64 ? kn - o0 : 64;
+            if (o0 > 0) __syncthreads();
+            for (int t = threadIdx.x; t < on; t += WG) {
+                const CONST_AS DevOp &d = ops[k + o0 + t];
+                s_opi[t][0] = d.lds_left;
+                s_opi[t][1] = d.lds_right;
+                s_opi[t][2] = d.left_kind == CHILD_LEAF;
+                s_opi[t][3] = d.right_kind == CHILD_LEAF;
+                s_opl[t][0] = op_child_len(d, 0);
+                s_opl[t][1] = op_child_len(d, 1);
             }
-            reg[B + q] = v;
+            __syncthreads();
+            for (int t = threadIdx.x; t < on * 2 * B; t += WG) {  // phase 1: exponentials
+                const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B;
+                s_reg[s_opi[o][child] + e] = exp(s_model[16 + (e & 3)] * (s_model[20 + (e >> 2)] * s_opl[o][child]));
+            }
+            __syncthreads();
+            c0a = T4_CLK();
+            for (int t = threadIdx.x; t < on * 2 * 5 * B; t += WG) {  // phase 2: leaf tables (K2)
+                const int o = t / (10 * B), r = t - o * (10 * B), child = r / (5 * B), q = r - child * (5 * B);
+                if (!s_opi[o][2 + child]) continue;
+                const int row = q / B, e = q - row * B, c = e >> 2, x = e & 3;
+                double *reg = s_reg + s_opi[o][child];
+                double v = 1.0;  // STATE_UNKNOWN row (phylokernel.h:228-232)
+                if (row < 4) {
+                    // E = U*ex rounded first, then the reference's (t0+t1)+(t2+t3), all unfused
+                    const double e0 = __dmul_rn(s_model[x * 4 + 0], reg[c * 4 + 0]);
+                    const double e1 = __dmul_rn(s_model[x * 4 + 1], reg[c * 4 + 1]);
+                    const double e2 = __dmul_rn(s_model[x * 4 + 2], reg[c * 4 + 2]);
+                    const double e3 = __dmul_rn(s_model[x * 4 + 3], reg[c * 4 + 3]);
+                    const double *tp = s_tip + row * 4;
+                    v = __dadd_rn(__dadd_rn(__dmul_rn(e0, tp[0]), __dmul_rn(e1, tp[1])),
+                                  __dadd_rn(__dmul_rn(e2, tp[2]), __dmul_rn(e3, tp[3])));
+                }
+                reg[B + q] = v;
+            }
         }
+        [[maybe_unused]] const unsigned long long c0b = T4_CLK();
         // phase 3: this thread's leaf state bytes of the whole chunk -> LDS.  They are read once per
         // traversal (cold misses); issuing them as one burst pays the miss latency once per chunk
         // instead of once per op and keeps the op loop's VMEM sequence short.
-        // (Unconditional requests, eight ops = sixteen bytes in flight at a time: sl / sr of a non-leaf child point at a valid
+        // (Unconditional requests, sixteen ops = thirty-two bytes in flight at a time: sl / sr of a non-leaf child point at a valid
         // row and its slot 0 is never read.  The conditional form -- load, wait, LDS store, next child -- paid one cold miss
         // per LEAF CHILD instead of per chunk: 87 k of a wave's 313 k cycles per traversal at 66 k patterns, measured with
         // the shader clock.)
         if (active) {
-            for (int o0 = 0; o0 < kn; o0 += 8) {
-                uint8_t vl[8], vr[8];
+            for (int o0 = 0; o0 < kn; o0 += 16) {
+                uint8_t vl[16], vr[16];
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
+                for (int j = 0; j < 16; j++) {
                     const CONST_AS DevOp *d = ops + (k + (o0 + j < kn ? o0 + j : kn - 1));
                     vl[j] = *(d->sl + poff);
                     vr[j] = *(d->sr + poff);
                 }
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
+                for (int j = 0; j < 16; j++) {
                     if (o0 + j < kn) {
                         const CONST_AS DevOp *d = ops + (k + o0 + j);
                         s_states[d->sl_slot * WG + threadIdx.x] = vl[j];
@@ -377,12 +412,19 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
         }
         __syncthreads();
         if (!active) { k += kn; continue; }
+#ifdef IQHIP_T4_TRACE
+        { const unsigned long long cz = T4_CLK(); t4_fill += cz - c0; t4_f1 += c0a - c0; t4_f2 += c0b - c0a; }
+#endif
 
         for (int kk = 0; kk < kn; kk++, k++) {
+            [[maybe_unused]] const unsigned long long c1 = T4_CLK();
             const CONST_AS DevOp *op = ops + k;
             const bool leafL = op->left_kind == CHILD_LEAF;
             const bool holdL = USE_HOLD && op->left_kind == CHILD_HOLD;
             const bool leafR = op->right_kind == CHILD_LEAF;
+            // (descriptor fields that only the op's tail needs: requested now, or the tail begins with their round trip)
+            int16_t *const dst_sc_p = op->dst_sc;
+            const int out_row = op->out_row, rule = op->no_scale, push_hold = op->push_hold;
             int sc = 0;
             // leaf states were staged into LDS when the chunk was filled
             const int sL = s_states[op->sl_slot * WG + threadIdx.x];
@@ -406,12 +448,13 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
             pf_sc = *reinterpret_cast<const int16_t *>(reinterpret_cast<const char *>(nx->pf_sc) +
                                                        ((nreal & 1) ? soff : (uint32_t)(lane * 2)));
             char *dstp = reinterpret_cast<char *>(op->dst) + voff;
+            [[maybe_unused]] const unsigned long long c2 = T4_CLK();
             double lh_max = node_update4<CL, C, USE_HOLD>(leafL, holdL, leafR, s_reg + op->lds_left, s_reg + op->lds_right,
                                                           s_tip, U, uinv, sL, sR, A.state_unknown, nx_pf, dstp, coff, PF, HOLD, prev);
             if (SP == 2) lh_max = fmax(lh_max, __shfl_xor(lh_max, 32, 64));  // both category halves of the pattern
+            [[maybe_unused]] const unsigned long long c3 = T4_CLK() + (lh_max == -1.0 ? 1 : 0);   // (after the update's results exist)
             // ---- scaling (SIMD rule, phylokernel.h:379-392,461-474); TIP-TIP never scales
             // (the last update of a multifurcating node carries the scalar kernel's rule: lh_max == 0 first, phylotreesse.cpp:774-788)
-            const int rule = op->no_scale;
             const bool zero = rule == 2 && !(leafL && leafR) && lh_max == 0.0;   // (TIP-TIP never scales, scalar kernel :807-843)
             const bool do_scale = zero || (!(leafL && leafR) && (lh_max < kScalingThreshold) && (invar == 0.0) && rule != 1);
             double my_scale = 0.0;
@@ -433,7 +476,7 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
                 }
             }
             prev_sc = sc;
-            if (USE_HOLD && op->push_hold) {
+            if (USE_HOLD && push_hold) {
                 // this result is the left child of a join a few ops ahead whose other subtree is a
                 // plain chain: park it in registers instead of re-reading 8 KiB per wave from memory
 #pragma unroll
@@ -441,17 +484,26 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
                 hold_sc = sc;
             }
 #ifndef IQHIP_ABLATE_NOSTORE
-            if (SP == 1 || lead) *reinterpret_cast<int16_t *>(reinterpret_cast<char *>(op->dst_sc) + soff) = (int16_t)sc;
+            if (SP == 1 || lead) *reinterpret_cast<int16_t *>(reinterpret_cast<char *>(dst_sc_p) + soff) = (int16_t)sc;
 #endif
             // deterministic reduction: wave partial -> slab[2+k][gw]
             double ws = 0.0;
             if (any) ws = wave_sum(my_scale);
             if (lane == 0) {
-                fold_store(&A.slab[(size_t)(2 + op->out_row) * A.nwaves + gw], ws);
-                if (any) fold_flag(A.fold, 2 + op->out_row);
+                fold_store(&A.slab[(size_t)(2 + out_row) * A.nwaves + gw], ws);
+                if (any) fold_flag(A.fold, 2 + out_row);
             }
+#ifdef IQHIP_T4_TRACE
+            { const unsigned long long c4 = T4_CLK(); t4_head += c2 - c1; t4_upd += c3 - c2; t4_tail += c4 - c3; t4_n++; }
+#endif
         }
     }
+#ifdef IQHIP_T4_TRACE
+    if (t4_on) {
+        atomicAdd(&g_t4[0], t4_fill); atomicAdd(&g_t4[1], t4_head); atomicAdd(&g_t4[2], t4_upd); atomicAdd(&g_t4[3], t4_tail);
+        atomicAdd(&g_t4[4], t4_n); atomicAdd(&g_t4[5], 1ull); atomicAdd(&g_t4[6], t4_f1); atomicAdd(&g_t4[7], t4_f2);
+    }
+#endif
     if (k_end == k_begin) __syncthreads();  // s_tip / s_val visibility for a root-only launch
     if (!active) return;   // (an exited wave no longer takes part in workgroup barriers)
 
@@ -517,7 +569,7 @@ static hipError_t launch_trav_h(iqhip_engine *e, Trav4Args &A) {
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(&k_traverse4<C, WG, HAS_LOAD, SP, USE_HOLD>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);  // (160 KB minus the static arrays of fold_tail)
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);  // (160 KB minus the static arrays: fold_tail, the fill's descriptor copies)
         attr_set = true;
     }
     constexpr int WPB = WG / 64;
@@ -555,6 +607,20 @@ static hipError_t launch_trav_wg(iqhip_engine *e, Trav4Args &A) {
 
 hipError_t launch_traverse4(iqhip_engine *e, const int *seg_table, int nsegs, bool has_load, const DevBranch *root, int nwaves,
                             int fold_rows) {
+#ifdef IQHIP_T4_TRACE
+    {
+        static int calls = 0;
+        if (++calls % 100 == 0) {
+            unsigned long long h[8];
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_t4), sizeof h);
+            if (h[4]) fprintf(stderr, "[t4] waves %llu ops %llu: per op head %.0f update %.0f tail %.0f clk; chunk fills %.0f clk per wave (exponentials %.0f, tables %.0f)\n",
+                              h[5], h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[3] / h[4], (double)h[0] / h[5], (double)h[6] / h[5], (double)h[7] / h[5]);
+            unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_t4), z, sizeof z);
+        }
+    }
+#endif
     Trav4Args A;
     A.fold.slab = e->d_slab;
     A.fold.result = e->d_result;
