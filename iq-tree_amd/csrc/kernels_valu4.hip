@@ -364,23 +364,25 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
             }
             __syncthreads();
             c0a = T4_CLK();
-            for (int t = threadIdx.x; t < on * 2 * 5 * B; t += WG) {  // phase 2: leaf tables (K2)
-                const int o = t / (10 * B), r = t - o * (10 * B), child = r / (5 * B), q = r - child * (5 * B);
+            // phase 2: leaf tables (K2).  One item = one (op, child, category, x): the four rounded products E = U[x][.] * ex are
+            // made once and serve the table's four state rows (A, C, G, T); the fifth row, STATE_UNKNOWN, is exactly 1.0
+            // (phylokernel.h:228-232).  (Entry by entry -- every entry remaking its E -- this phase was 14.6 k of a wave's cycles.)
+            for (int t = threadIdx.x; t < on * 2 * B; t += WG) {
+                const int o = t / (2 * B), r = t - o * (2 * B), child = r / B, e = r - child * B, c = e >> 2, x = e & 3;
                 if (!s_opi[o][2 + child]) continue;
-                const int row = q / B, e = q - row * B, c = e >> 2, x = e & 3;
                 double *reg = s_reg + s_opi[o][child];
-                double v = 1.0;  // STATE_UNKNOWN row (phylokernel.h:228-232)
-                if (row < 4) {
-                    // E = U*ex rounded first, then the reference's (t0+t1)+(t2+t3), all unfused
-                    const double e0 = __dmul_rn(s_model[x * 4 + 0], reg[c * 4 + 0]);
-                    const double e1 = __dmul_rn(s_model[x * 4 + 1], reg[c * 4 + 1]);
-                    const double e2 = __dmul_rn(s_model[x * 4 + 2], reg[c * 4 + 2]);
-                    const double e3 = __dmul_rn(s_model[x * 4 + 3], reg[c * 4 + 3]);
+                // E = U*ex rounded first, then the reference's (t0+t1)+(t2+t3), all unfused
+                const double e0 = __dmul_rn(s_model[x * 4 + 0], reg[c * 4 + 0]);
+                const double e1 = __dmul_rn(s_model[x * 4 + 1], reg[c * 4 + 1]);
+                const double e2 = __dmul_rn(s_model[x * 4 + 2], reg[c * 4 + 2]);
+                const double e3 = __dmul_rn(s_model[x * 4 + 3], reg[c * 4 + 3]);
+#pragma unroll
+                for (int row = 0; row < 4; row++) {
                     const double *tp = s_tip + row * 4;
-                    v = __dadd_rn(__dadd_rn(__dmul_rn(e0, tp[0]), __dmul_rn(e1, tp[1])),
-                                  __dadd_rn(__dmul_rn(e2, tp[2]), __dmul_rn(e3, tp[3])));
+                    reg[B + row * B + e] = __dadd_rn(__dadd_rn(__dmul_rn(e0, tp[0]), __dmul_rn(e1, tp[1])),
+                                                     __dadd_rn(__dmul_rn(e2, tp[2]), __dmul_rn(e3, tp[3])));
                 }
-                reg[B + q] = v;
+                reg[B + 4 * B + e] = 1.0;
             }
         }
         [[maybe_unused]] const unsigned long long c0b = T4_CLK();
