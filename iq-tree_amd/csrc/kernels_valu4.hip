@@ -393,6 +393,24 @@ __global__ __launch_bounds__(WG, 2) void k_traverse4(const Trav4Args A) {
         // row and its slot 0 is never read.  The conditional form -- load, wait, LDS store, next child -- paid one cold miss
         // per LEAF CHILD instead of per chunk: 87 k of a wave's 313 k cycles per traversal at 66 k patterns, measured with
         // the shader clock.)
+        // One lane per pattern (SP = 1): the wave's 64 state bytes of a leaf child are 16 dwords, which `global_load_lds_dword`
+        // moves straight into LDS (lane i's dword lands at base + 4 i: tools/lds_load_probe.hip) -- no registers, every
+        // request of the chunk in flight at once, one wait.  (Through registers, 32 bytes in flight at a time, the staging
+        // was 22 k of a wave's 230 k cycles per traversal.)
+        if constexpr (SP == 1) {
+            if (active && lane < 16) {
+                for (int o = 0; o < kn; o++) {
+                    const CONST_AS DevOp *d = ops + (k + o);
+                    if (d->left_kind == CHILD_LEAF)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(d->sl + tl * 64 + 4 * lane),
+                                                         (__attribute__((address_space(3))) void *)(s_states + d->sl_slot * WG + wave * 64), 4, 0, 0);
+                    if (d->right_kind == CHILD_LEAF)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(d->sr + tl * 64 + 4 * lane),
+                                                         (__attribute__((address_space(3))) void *)(s_states + d->sr_slot * WG + wave * 64), 4, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else
         if (active) {
             for (int o0 = 0; o0 < kn; o0 += 16) {
                 uint8_t vl[16], vr[16];
