@@ -1296,7 +1296,7 @@ static int build_plan(iqhip_engine *e, const iqhip_node_op *ops, int nops, int *
             if (e->mfma_pipelined && e->n == 64) fixed = std::max(fixed, (e->state_unknown + 1) * e->n + 4 * 16 * 64 + 128);
             // two workgroups per CU (160 KB LDS): <= 78 KB each, images included (a third workgroup
             // for the 20-state kernel was measured: no gain, more chunks); IQHIP_MFMA_LDS_KB overrides
-            int total_kb = 78;
+            int total_kb = e->n == 20 ? 75 : 78;   // (20 states: + 2.6 KB of static arrays per workgroup, the fill's descriptor copies)
             if (const char *kb = getenv("IQHIP_MFMA_LDS_KB")) total_kb = atoi(kb);
             if (e->plan_nhold > 0) fixed += 4 * 16 * B;   // the waves' parking places (CHILD_HOLD in LDS)
             budget = (total_kb * 1024) / 8 - fixed;
