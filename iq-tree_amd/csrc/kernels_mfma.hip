@@ -671,8 +671,9 @@ __device__ __forceinline__ void trav_mfma2_body(const TravMArgs &A, const int vb
             // dummy rows): fetched at the op itself, the first products of every leaf op waited out an L2 round trip
             int sc = 0;
             const int sL = sLn, sR = sRn;
-            sLn = nxop.sl[ptn];
-            sRn = nxop.sr[ptn];
+            // (only for leaf children: requests to the dummy rows of the others cost 1.3 % of the protein traversal)
+            if (nxop.left_kind == CHILD_LEAF) sLn = nxop.sl[ptn];
+            if (nxop.right_kind == CHILD_LEAF) sRn = nxop.sr[ptn];
             const bool holdL = HOLDS && op.left_kind == CHILD_HOLD;
             const bool push = HOLDS && op.push_hold;
             // CHERRY: both children are leaves and the engine holds the node's vector for every pair of leaf states (L2 /
